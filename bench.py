@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — MLUPS of the D2Q9-BGK timestep (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one loop body of Solver::run (exchange + stream + BCs + stability + collision, one fused kernel
+launch) over the whole lattice. Workload at every N: BASELINE.json configs[2], the 4096x1024 fp64 cylinder at
+Re=200 (tau=0.6, u_in=0.06510417) — the grid the metric is quoted on ("4096x1024 D2Q9 at 1/2/4/8 GPUs"), so
+N>1 is STRONG scaling: the rows are cut into N strips, one process per GPU, edge rows exchanged with RCCL
+send/recv each step. Populations are resident in HBM before the timed region; nothing is copied to the host
+inside it and no output (forces/VTK) step falls inside it.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (live HIP-event kernel time on
+the library's own stream) and, at N=1, `cpu_baseline` (the reference binary oracle/_ref/ref_driver if it runs
+on this host, else the oracle port; bounded sample).
+"""
+import argparse
+import importlib
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "highperformancecomputing-latticeboltzmannmethod_amd"
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_LUP = {"f64": 144, "f32": 72}   # 9 loads + 9 stores per lattice update
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(nx, ny, u_in, budget_s=12.0):
+    """Reported baseline only: the reference's CPU path on this host's cores, bounded sample of the same grid."""
+    cores = host_cores()
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="true")
+    if os.path.exists(ref):
+        try:
+            import tempfile
+            d = tempfile.mkdtemp(prefix="lbmref_")
+            best = None
+            for steps in (5, None):
+                if steps is None:
+                    steps = max(5, min(400, int(budget_s * best * 1e6 / (nx * ny)))) if best else 20
+                out = subprocess.run([ref, "--nx", str(nx), "--ny", str(ny), "--steps", str(steps), "--of", "1000000",
+                                      "--tau", "0.6", "--u", repr(u_in), "--time"], cwd=d, env=env, timeout=300,
+                                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                m = re.search(r"REFTIME .*threads=(\d+) seconds=([\d.]+) mlups=([\d.]+) ok=1", out.stdout)
+                if not m:
+                    raise RuntimeError(out.stderr[-300:])
+                best = float(m.group(3))
+                threads = int(m.group(1))
+            return {"value": round(best, 2), "unit": "MLUPS", "cores": threads, "kind": "reference",
+                    "sample": f"unmodified reference (oracle/_ref/ref_driver, -O3 -ffast-math -mavx2 -mfma -fopenmp), "
+                              f"{nx}x{ny} fp64, {steps} steps incl. its per-step stability scan, 1 MPI rank x {threads} OpenMP threads"}
+        except Exception as e:  # the reference binary does not run on this host: time the port instead
+            sys.stderr.write(f"[bench] reference binary unusable here ({e}); timing the oracle port\n")
+    from oracle.oracle import Oracle, make_params
+    o = Oracle(make_params(nx, ny, inlet_velocity=u_in))
+    t0 = time.perf_counter(); o.run(3); dt = (time.perf_counter() - t0) / 3
+    steps = max(5, min(200, int(budget_s / dt)))
+    t0 = time.perf_counter(); o.run(steps); dt = time.perf_counter() - t0
+    threads = o.L.lbmo_threads()
+    o.close()
+    return {"value": round(nx * ny * steps / dt / 1e6, 2), "unit": "MLUPS", "cores": threads, "kind": "port",
+            "sample": f"oracle/lbm_oracle.c (CPU restatement, same phase structure as the reference), {nx}x{ny} fp64, "
+                      f"{steps} steps, {threads} OpenMP threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--nx", type=int, default=4096)
+    ap.add_argument("--ny", type=int, default=1024)
+    ap.add_argument("--re", type=float, default=200.0)
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: the named grid cut into N strips (BASELINE metric); weak: ny rows PER GPU")
+    ap.add_argument("--variant", type=int, default=None, help="kernel variant (tuning)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    lbm = importlib.import_module(PKG)
+    if lbm.device_count() < 1:
+        sys.exit("no HIP device: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    nx = args.nx
+    ny_total = args.ny * (world if args.scaling == "weak" else 1)
+    if ny_total % world:
+        sys.exit(f"ny={ny_total} not divisible by {world} strips")
+    local_ny = ny_total // world
+    # keep tau = 0.6 (nu = 1/30) and set u_in so that params.reynolds() == Re
+    u_in = args.re * ((0.6 - 0.5) / 3.0) / (2.0 * 0.05 * ny_total)
+
+    ctx = lbm.Context(nx, ny_total, tau=0.6, inlet_velocity=u_in, y_start=rank * local_ny, local_ny=local_ny,
+                      precision=args.precision, device=local_rank)
+    if args.variant is not None:
+        ctx.set_option("variant", args.variant)
+    if world > 1:
+        ident = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        ctx.comm_init(rank, world, ident[0])
+    ctx.initialise()
+    ctx.set_option("timing", 1)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    ctx.step(args.warmup, 0)
+    fence()
+    t0 = time.perf_counter()
+    ctx.step(args.steps, 0)
+    fence()
+    dt = time.perf_counter() - t0
+    kernel_ms = ctx.last_step_kernel_ms()
+    if world > 1:
+        tt = torch.tensor([dt, kernel_ms], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, kernel_ms = float(tt[0]), float(tt[1])
+    bad = ctx.first_unstable_step()
+    if bad != -1:
+        sys.exit(f"simulation unstable at timestep {bad}: result invalid")
+
+    if rank == 0:
+        cells = nx * ny_total
+        mlups = cells * args.steps / dt / 1e6
+        bpl = BYTES_PER_LUP[args.precision]
+        # dominant kernel: one launch updates this rank's strip; algorithmic bytes per launch / mean launch time
+        launch_bytes = nx * local_ny * bpl
+        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                key = f"{nx}x{local_ny}_{args.precision}"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "MLUPS", "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"D2Q9-BGK cylinder Re={args.re:g}, {nx}x{ny_total} {args.precision}, tau=0.6, "
+                                   f"u_in={u_in:.8f} (BASELINE.json configs[2])",
+                       "nx": nx, "ny": ny_total, "rows_per_gpu": local_ny, "decomposition": f"{world} row strip(s)",
+                       "halo": "none" if world == 1 else "RCCL send/recv, 3 populations x 1 row per face",
+                       "kernel": ctx.kernel_name()},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": ctx.kernel_name(), "kernel_ms": round(kernel_ms, 5),
+                         "algorithmic_bytes_per_launch": launch_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(nx, ny_total, u_in)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,606 @@
+// csrc/lbm_hip.hip — host side of liblbm_hip.so: the C-ABI of include/lbm_hip.h over the gfx950 kernels in
+// lbm_kernels.hpp. Plain HIP runtime + RCCL; no torch types, no CPU fallback.
+#include "lbm_kernels.hpp"
+#include "../../include/lbm_hip.h"
+
+#include <rccl/rccl.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace lbmk;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(LBM_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, \
+                                          hipGetErrorString(e_));                                 \
+    } while (0)
+#define NCCLCHK(expr)                                                                               \
+    do {                                                                                            \
+        ncclResult_t r_ = (expr);                                                                   \
+        if (r_ != ncclSuccess) return fail(LBM_ERR_COMM, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, \
+                                           ncclGetErrorString(r_));                                 \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct lbm_ctx {
+    lbm_params p{};
+    int device = 0;
+    hipStream_t stream = nullptr;       // compute stream (all kernels)
+    hipStream_t comm_stream = nullptr;  // halo exchange (RCCL send/recv)
+    hipEvent_t ev_edge = nullptr, ev_comm = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    int nx = 0, nyl = 0, pitch = 0, xoff = 0;
+    size_t plane = 0;        // elements per plane
+    size_t esize = 8;        // bytes per element
+    void* buf[2] = {nullptr, nullptr};
+    int cur = 0;             // buf[cur] = P_{steps_done}; buf[cur^1] = P_{steps_done-1} (or the initial state)
+    void* scratch = nullptr; // f_current snapshot (lazy)
+    double* d_macro = nullptr;   // rho | ux | uy (lazy), each nx*nyl
+    unsigned long long* d_maxbits = nullptr;
+    int* d_unstable = nullptr;
+    int* d_solid_count = nullptr;
+    double* d_force_now = nullptr;  // 3 doubles
+    double* d_force_log = nullptr;  // capacity x 3 doubles
+    int log_cap = 0, log_count = 0;
+    int steps_done = 0;
+    bool initialised = false;
+    double feq_in[Q];
+    int cyl_x = 0, cyl_y = 0, cyl_r = 0;
+    // options
+    int variant = 0;
+    int timing = 0;
+    int overlap = 1;
+    int timed_launches = 0;
+    // communicator
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    double* d_red = nullptr;
+    // host-staged halo staging (device side)
+    double* d_halo = nullptr;  // 4 x 3 x nx doubles
+};
+
+namespace {
+
+template <typename T>
+KArgs<T> make_kargs(const lbm_ctx* c, int src, int dst, int t) {
+    KArgs<T> a;
+    a.src = static_cast<const T*>(c->buf[src]);
+    a.dst = static_cast<T*>(c->buf[dst]);
+    a.plane = (long)c->plane;
+    a.pitch = c->pitch;
+    a.xoff = c->xoff;
+    a.nx = c->nx;
+    a.ny_loc = c->nyl;
+    a.ny_glob = c->p.ny;
+    a.y_start = c->p.y_start;
+    a.cyl_x = c->cyl_x;
+    a.cyl_y = c->cyl_y;
+    a.cyl_r2 = (double)(c->cyl_r * c->cyl_r);
+    a.tau_inv = (T)(1.0 / c->p.tau);
+    a.u_in = (T)c->p.inlet_velocity;
+    a.unstable_t = c->d_unstable;
+    a.t = t;
+    return a;
+}
+
+// Launch one step-family kernel over rows [y0, y0+ny) of the strip.
+template <typename T, int MODE>
+void launch_site(const lbm_ctx* c, KArgs<T> a, hipStream_t s) {
+    dim3 grid((c->nx + 255) / 256, c->nyl), block(256);
+    hipLaunchKernelGGL((k_step_site<T, MODE>), grid, block, 0, s, a);
+}
+
+template <typename T>
+int launch_step(lbm_ctx* c, int src, int dst, int t, int mode, hipStream_t s) {
+    KArgs<T> a = make_kargs<T>(c, src, dst, t);
+    switch (mode) {
+        case MODE_STEP: launch_site<T, MODE_STEP>(c, a, s); break;
+        case MODE_COLLIDE_ONLY: launch_site<T, MODE_COLLIDE_ONLY>(c, a, s); break;
+        default: break;
+    }
+    HIPCHK(hipGetLastError());
+    return LBM_OK;
+}
+
+template <typename T>
+int launch_forces(lbm_ctx* c, double* out, int t) {
+    ForceArgs<T> f;
+    f.cur = static_cast<const T*>(c->buf[c->cur]);
+    f.plane = (long)c->plane; f.pitch = c->pitch; f.xoff = c->xoff;
+    f.nx = c->nx; f.ny_loc = c->nyl; f.ny_glob = c->p.ny; f.y_start = c->p.y_start;
+    f.cyl_x = c->cyl_x; f.cyl_y = c->cyl_y; f.cyl_r = c->cyl_r; f.cyl_r2 = (double)(c->cyl_r * c->cyl_r);
+    f.x0 = std::max(0, c->cyl_x - c->cyl_r - 1);
+    f.x1 = std::min(c->nx - 1, c->cyl_x + c->cyl_r + 1);
+    f.y0 = std::max(0, c->cyl_y - c->cyl_r - 1 - c->p.y_start);
+    f.y1 = std::min(c->nyl - 1, c->cyl_y + c->cyl_r + 1 - c->p.y_start);
+    f.out = out; f.t = t;
+    hipLaunchKernelGGL((k_forces<T>), dim3(1), dim3(1024), 0, c->stream, f);
+    HIPCHK(hipGetLastError());
+    return LBM_OK;
+}
+
+// ---- halo exchange over RCCL -------------------------------------------------------------------------
+// After K_t has produced P_{t+1} in buf[dst]: my top interior row's {2,5,6} go to the north neighbour's south
+// ghost row, my bottom interior row's {4,7,8} to the south neighbour's north ghost row. In SoA
+// each is a contiguous run of nx elements, so there is no pack kernel; 3 sends + 3 recvs per face in one group.
+template <typename T>
+int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
+    if (c->nranks <= 1) return LBM_OK;
+    T* base = static_cast<T*>(c->buf[dst]);
+    const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+    const long row_top = (long)c->nyl * c->pitch + c->xoff;        // top interior row (gy = nyl)
+    const long row_bot = (long)1 * c->pitch + c->xoff;             // bottom interior row (gy = 1)
+    const long ghost_n = (long)(c->nyl + 1) * c->pitch + c->xoff;  // north ghost row
+    const long ghost_s = (long)c->xoff;                            // south ghost row (gy = 0)
+    const int up[3] = {2, 5, 6}, down[3] = {4, 7, 8};
+    NCCLCHK(ncclGroupStart());
+    if (c->rank + 1 < c->nranks) {
+        for (int k = 0; k < 3; ++k) {
+            NCCLCHK(ncclSend(base + (long)up[k] * c->plane + row_top, c->nx, dt, c->rank + 1, c->comm, s));
+            NCCLCHK(ncclRecv(base + (long)down[k] * c->plane + ghost_n, c->nx, dt, c->rank + 1, c->comm, s));
+        }
+    }
+    if (c->rank > 0) {
+        for (int k = 0; k < 3; ++k) {
+            NCCLCHK(ncclSend(base + (long)down[k] * c->plane + row_bot, c->nx, dt, c->rank - 1, c->comm, s));
+            NCCLCHK(ncclRecv(base + (long)up[k] * c->plane + ghost_s, c->nx, dt, c->rank - 1, c->comm, s));
+        }
+    }
+    NCCLCHK(ncclGroupEnd());
+    return LBM_OK;
+}
+
+template <typename T>
+int do_initialise(lbm_ctx* c) {
+    InitArgs<T> ia;
+    ia.a = static_cast<T*>(c->buf[0]);
+    ia.b = static_cast<T*>(c->buf[1]);
+    ia.plane = (long)c->plane; ia.pitch = c->pitch; ia.xoff = c->xoff;
+    ia.nx = c->nx; ia.ny_loc = c->nyl; ia.ny_glob = c->p.ny; ia.y_start = c->p.y_start;
+    ia.cyl_x = c->cyl_x; ia.cyl_y = c->cyl_y; ia.cyl_r2 = (double)(c->cyl_r * c->cyl_r);
+    for (int i = 0; i < Q; ++i) ia.feq_in[i] = (T)c->feq_in[i];
+    ia.solid_count = c->d_solid_count;
+    HIPCHK(hipMemsetAsync(c->d_solid_count, 0, sizeof(int), c->stream));
+    dim3 grid((c->nx + 2 + 255) / 256, c->nyl + 2), block(256);
+    hipLaunchKernelGGL((k_init<T>), grid, block, 0, c->stream, ia);
+    HIPCHK(hipGetLastError());
+    // collision_step of iteration 0: initial state (buf 0) -> P_0 (buf 1)
+    int rc = launch_step<T>(c, 0, 1, 0, MODE_COLLIDE_ONLY, c->stream);
+    if (rc) return rc;
+    c->cur = 1;
+    if (c->comm) {
+        rc = exchange_rccl<T>(c, c->cur, c->stream);
+        if (rc) return rc;
+    }
+    return LBM_OK;
+}
+
+template <typename T>
+int do_steps(lbm_ctx* c, int nsteps, int of) {
+    if (c->timing) HIPCHK(hipEventRecord(c->ev_t0, c->stream));
+    for (int k = 0; k < nsteps; ++k) {
+        const int t = c->steps_done;
+        if (of > 0 && t % of == 0) {
+            if (c->log_count >= c->log_cap) return fail(LBM_ERR_ARG, "force log full (%d rows): drain it", c->log_cap);
+            int rc = launch_forces<T>(c, c->d_force_log + 3L * c->log_count, t);
+            if (rc) return rc;
+            c->log_count++;
+        }
+        const int src = c->cur, dst = c->cur ^ 1;
+        int rc = launch_step<T>(c, src, dst, t, MODE_STEP, c->stream);
+        if (rc) return rc;
+        if (c->comm) {
+            rc = exchange_rccl<T>(c, dst, c->stream);
+            if (rc) return rc;
+        }
+        c->cur = dst;
+        c->steps_done = t + 1;
+    }
+    if (c->timing) {
+        HIPCHK(hipEventRecord(c->ev_t1, c->stream));
+        c->timed_launches = nsteps;
+    }
+    return LBM_OK;
+}
+
+template <typename T>
+int do_macros(lbm_ctx* c, bool want_max) {
+    const size_t n = (size_t)c->nx * c->nyl;
+    if (!c->d_macro) HIPCHK(hipMalloc(&c->d_macro, 3 * n * sizeof(double)));
+    MacroArgs<T> m;
+    m.old = static_cast<const T*>(c->buf[c->cur ^ 1]);
+    m.plane = (long)c->plane; m.pitch = c->pitch; m.xoff = c->xoff;
+    m.nx = c->nx; m.ny_loc = c->nyl; m.ny_glob = c->p.ny; m.y_start = c->p.y_start;
+    m.cyl_x = c->cyl_x; m.cyl_y = c->cyl_y; m.cyl_r2 = (double)(c->cyl_r * c->cyl_r);
+    m.u_in = (T)c->p.inlet_velocity;
+    m.initial = (c->steps_done == 0);
+    m.rho = c->d_macro; m.ux = c->d_macro + n; m.uy = c->d_macro + 2 * n;
+    m.max_usq_bits = want_max ? c->d_maxbits : nullptr;
+    if (want_max) HIPCHK(hipMemsetAsync(c->d_maxbits, 0, sizeof(unsigned long long), c->stream));
+    dim3 grid((c->nx + 255) / 256, c->nyl), block(256);
+    hipLaunchKernelGGL((k_macros<T>), grid, block, 0, c->stream, m);
+    HIPCHK(hipGetLastError());
+    return LBM_OK;
+}
+
+template <typename T>
+int do_populations(lbm_ctx* c, int which, double* aos) {
+    const int tnx = c->nx + 2, tny = c->nyl + 2;
+    const void* srcbuf = c->buf[c->cur ^ 1];
+    const bool initial = (c->steps_done == 0);
+    if (which == 0 && !initial) {
+        if (!c->scratch) HIPCHK(hipMalloc(&c->scratch, Q * c->plane * c->esize));
+        KArgs<T> a = make_kargs<T>(c, c->cur ^ 1, c->cur ^ 1, 0);
+        a.dst = static_cast<T*>(c->scratch);
+        launch_site<T, MODE_STREAM_ONLY>(c, a, c->stream);
+        HIPCHK(hipGetLastError());
+        srcbuf = c->scratch;
+    }
+    std::vector<T> host(Q * c->plane);
+    HIPCHK(hipMemcpyAsync(host.data(), srcbuf, Q * c->plane * c->esize, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int gy = 0; gy < tny; ++gy)
+        for (int gx = 0; gx < tnx; ++gx) {
+            const bool ghost = (gy == 0 || gy == tny - 1 || gx == 0 || gx == tnx - 1);
+            double* o = aos + ((size_t)gy * tnx + gx) * Q;
+            // ghost cells of f_current are never written after Grid::initialise (LBMGrid.h:196-213); those of
+            // f_next keep the initial equilibrium until the first exchange_ghost_cells
+            const bool analytic = ghost && (which == 0 || initial);
+            for (int i = 0; i < Q; ++i)
+                o[i] = analytic ? (double)(T)c->feq_in[i]
+                                : (double)host[(size_t)i * c->plane + (size_t)gy * c->pitch + c->xoff + gx - 1];
+        }
+    return LBM_OK;
+}
+
+template <typename T>
+int do_halo_export(lbm_ctx* c, double* south_out, double* north_out) {
+    const T* base = static_cast<const T*>(c->buf[c->cur]);
+    const size_t n3 = 3 * (size_t)c->nx;
+    dim3 grid((c->nx + 255) / 256), block(256);
+    if (south_out) {
+        hipLaunchKernelGGL((k_halo_pack<T>), grid, block, 0, c->stream, base, (long)c->plane,
+                           (long)1 * c->pitch + c->xoff, c->nx, 4, 7, 8, c->d_halo);
+        HIPCHK(hipMemcpyAsync(south_out, c->d_halo, n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (north_out) {
+        hipLaunchKernelGGL((k_halo_pack<T>), grid, block, 0, c->stream, base, (long)c->plane,
+                           (long)c->nyl * c->pitch + c->xoff, c->nx, 2, 5, 6, c->d_halo + n3);
+        HIPCHK(hipMemcpyAsync(north_out, c->d_halo + n3, n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LBM_OK;
+}
+
+template <typename T>
+int do_halo_import(lbm_ctx* c, const double* south_in, const double* north_in) {
+    T* base = static_cast<T*>(c->buf[c->cur]);
+    const size_t n3 = 3 * (size_t)c->nx;
+    dim3 grid((c->nx + 255) / 256), block(256);
+    if (south_in) {
+        HIPCHK(hipMemcpyAsync(c->d_halo + 2 * n3, south_in, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL((k_halo_unpack<T>), grid, block, 0, c->stream, base, (long)c->plane, (long)c->xoff, c->nx,
+                           2, 5, 6, c->d_halo + 2 * n3);
+    }
+    if (north_in) {
+        HIPCHK(hipMemcpyAsync(c->d_halo + 3 * n3, north_in, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL((k_halo_unpack<T>), grid, block, 0, c->stream, base, (long)c->plane,
+                           (long)(c->nyl + 1) * c->pitch + c->xoff, c->nx, 4, 7, 8, c->d_halo + 3 * n3);
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LBM_OK;
+}
+
+#define DISPATCH(c, call_d, call_f) ((c)->p.precision == LBM_PRECISION_F32 ? (call_f) : (call_d))
+
+}  // namespace
+
+extern "C" {
+
+const char* lbm_last_error(void) { return g_err; }
+
+int lbm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
+    if (!p || !out) return fail(LBM_ERR_ARG, "null argument");
+    if (p->nx < 1 || p->ny < 1 || !(p->tau > 0.0)) return fail(LBM_ERR_ARG, "bad nx/ny/tau");
+    if (p->precision != LBM_PRECISION_F64 && p->precision != LBM_PRECISION_F32)
+        return fail(LBM_ERR_ARG, "bad precision %d", p->precision);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(LBM_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(LBM_ERR_ARG, "device %d out of range (%d devices)", device, ndev);
+    lbm_ctx* c = new (std::nothrow) lbm_ctx();
+    if (!c) return fail(LBM_ERR_ALLOC, "out of host memory");
+    c->p = *p;
+    if (c->p.local_ny <= 0) c->p.local_ny = p->ny - p->y_start;
+    if (c->p.y_start < 0 || c->p.y_start + c->p.local_ny > p->ny || c->p.local_ny < 1) {
+        delete c;
+        return fail(LBM_ERR_ARG, "strip [%d,%d) outside [0,%d)", p->y_start, p->y_start + p->local_ny, p->ny);
+    }
+    c->device = device;
+    c->nx = p->nx;
+    c->nyl = c->p.local_ny;
+    c->esize = p->precision == LBM_PRECISION_F32 ? 4 : 8;
+    const int per128 = (int)(128 / c->esize);
+    c->xoff = per128;                                      // interior x=0 starts a 128-byte line
+    c->pitch = round_up(c->xoff + c->nx + 1, per128);      // ghost column x=nx fits, rows stay 128-B aligned
+    c->plane = (size_t)c->pitch * (c->nyl + 2);
+    // LBMConfig.h:61-65: truncation toward zero
+    c->cyl_x = (int)(p->cylinder_x * p->nx);
+    c->cyl_y = (int)(p->cylinder_y * p->ny);
+    c->cyl_r = (int)(p->cylinder_radius * p->ny);
+    {   // f_eq(rho=1, u=(u_in,0)) as Grid::initialise evaluates it (LBMUtils.h:9-12,22-65)
+        const double ux = p->inlet_velocity, uy = 0.0, rho = 1.0;
+        const double usq = ux * ux + uy * uy, t3 = 1.5 * usq;
+        c->feq_in[0] = wgt<double>(0) * rho * (1.0 - 1.5 * usq);
+        for (int i = 1; i < Q; ++i) {
+            const double cu = (double)cx(i) * ux + (double)cy(i) * uy;
+            c->feq_in[i] = (wgt<double>(i) * rho) * (((1.0 + 3.0 * cu) - t3) + 4.5 * (cu * cu));
+        }
+    }
+    c->log_cap = p->force_log_capacity > 0 ? p->force_log_capacity : 4096;
+    auto bail = [&](int code) { lbm_destroy(c); return code; };
+#define HIPTRY(expr)                                                                                             \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess)                                                                                    \
+            return bail(fail(LBM_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)));  \
+    } while (0)
+    HIPTRY(hipSetDevice(device));
+    HIPTRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPTRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIPTRY(hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
+    HIPTRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+    HIPTRY(hipEventCreate(&c->ev_t0));
+    HIPTRY(hipEventCreate(&c->ev_t1));
+    const size_t bytes = Q * c->plane * c->esize;
+    HIPTRY(hipMalloc(&c->buf[0], bytes));
+    HIPTRY(hipMalloc(&c->buf[1], bytes));
+    HIPTRY(hipMalloc(&c->d_unstable, sizeof(int)));
+    HIPTRY(hipMalloc(&c->d_solid_count, sizeof(int)));
+    HIPTRY(hipMalloc(&c->d_maxbits, sizeof(unsigned long long)));
+    HIPTRY(hipMalloc(&c->d_force_now, 3 * sizeof(double)));
+    HIPTRY(hipMalloc(&c->d_force_log, 3 * sizeof(double) * c->log_cap));
+    HIPTRY(hipMalloc(&c->d_halo, 4 * 3 * sizeof(double) * (size_t)c->nx));
+    HIPTRY(hipMalloc(&c->d_red, 64 * sizeof(double)));
+#undef HIPTRY
+    *out = c;
+    return LBM_OK;
+}
+
+void lbm_destroy(lbm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    if (c->comm) ncclCommDestroy(c->comm);
+    void* ptrs[] = {c->buf[0], c->buf[1], c->scratch, c->d_macro, c->d_maxbits, c->d_unstable, c->d_solid_count,
+                    c->d_force_now, c->d_force_log, c->d_halo, c->d_red};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    hipEvent_t evs[] = {c->ev_edge, c->ev_comm, c->ev_t0, c->ev_t1};
+    for (hipEvent_t e : evs)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    delete c;
+}
+
+int lbm_initialise(lbm_ctx* c, int* solid_count_out) {
+    if (!c) return fail(LBM_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    const int big = INT_MAX;
+    HIPCHK(hipMemcpyAsync(c->d_unstable, &big, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->steps_done = 0;
+    c->log_count = 0;
+    int rc = DISPATCH(c, do_initialise<double>(c), do_initialise<float>(c));
+    if (rc) return rc;
+    int sc = 0;
+    HIPCHK(hipMemcpyAsync(&sc, c->d_solid_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (solid_count_out) *solid_count_out = sc;
+    c->initialised = true;
+    return LBM_OK;
+}
+
+int lbm_step(lbm_ctx* c, int nsteps, int output_frequency) {
+    if (!c || !c->initialised) return fail(LBM_ERR_ARG, "context not initialised");
+    if (nsteps < 0) return fail(LBM_ERR_ARG, "nsteps < 0");
+    HIPCHK(hipSetDevice(c->device));
+    return DISPATCH(c, do_steps<double>(c, nsteps, output_frequency), do_steps<float>(c, nsteps, output_frequency));
+}
+
+int lbm_sync(lbm_ctx* c) {
+    if (!c) return fail(LBM_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LBM_OK;
+}
+
+int lbm_steps_done(const lbm_ctx* c) { return c ? c->steps_done : -1; }
+
+int lbm_first_unstable_step(lbm_ctx* c, int* t_out) {
+    if (!c || !t_out) return fail(LBM_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    int v = INT_MAX;
+    HIPCHK(hipMemcpyAsync(&v, c->d_unstable, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *t_out = (v == INT_MAX) ? -1 : v;
+    return LBM_OK;
+}
+
+int lbm_get_forces(lbm_ctx* c, double* fx, double* fy) {
+    if (!c || !c->initialised) return fail(LBM_ERR_ARG, "context not initialised");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = DISPATCH(c, launch_forces<double>(c, c->d_force_now, c->steps_done),
+                      launch_forces<float>(c, c->d_force_now, c->steps_done));
+    if (rc) return rc;
+    double h[3];
+    HIPCHK(hipMemcpyAsync(h, c->d_force_now, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (fx) *fx = h[1];
+    if (fy) *fy = h[2];
+    return LBM_OK;
+}
+
+int lbm_drain_force_log(lbm_ctx* c, lbm_force_row* rows, int max_rows) {
+    if (!c || (!rows && max_rows > 0)) return fail(LBM_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    const int n = std::min(max_rows, c->log_count);
+    if (n < c->log_count) return fail(LBM_ERR_ARG, "force log holds %d rows, buffer takes %d", c->log_count, max_rows);
+    std::vector<double> h(3 * (size_t)std::max(n, 1));
+    if (n > 0) HIPCHK(hipMemcpyAsync(h.data(), c->d_force_log, 3 * sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < n; ++k) {
+        rows[k].timestep = (int)h[3 * k];
+        rows[k].fx = h[3 * k + 1];
+        rows[k].fy = h[3 * k + 2];
+    }
+    c->log_count = 0;
+    return n;
+}
+
+int lbm_get_macros(lbm_ctx* c, double* rho, double* ux, double* uy) {
+    if (!c || !c->initialised) return fail(LBM_ERR_ARG, "context not initialised");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = DISPATCH(c, do_macros<double>(c, false), do_macros<float>(c, false));
+    if (rc) return rc;
+    const size_t n = (size_t)c->nx * c->nyl;
+    if (rho) HIPCHK(hipMemcpyAsync(rho, c->d_macro, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (ux) HIPCHK(hipMemcpyAsync(ux, c->d_macro + n, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (uy) HIPCHK(hipMemcpyAsync(uy, c->d_macro + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LBM_OK;
+}
+
+int lbm_max_velocity_sq(lbm_ctx* c, double* out) {
+    if (!c || !c->initialised || !out) return fail(LBM_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = DISPATCH(c, do_macros<double>(c, true), do_macros<float>(c, true));
+    if (rc) return rc;
+    unsigned long long bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, c->d_maxbits, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(out, &bits, sizeof(double));
+    return LBM_OK;
+}
+
+int lbm_get_populations(lbm_ctx* c, int which, double* aos) {
+    if (!c || !c->initialised || !aos || (which != 0 && which != 1)) return fail(LBM_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    return DISPATCH(c, do_populations<double>(c, which, aos), do_populations<float>(c, which, aos));
+}
+
+int lbm_get_solid(lbm_ctx* c, unsigned char* mask) {
+    if (!c || !mask) return fail(LBM_ERR_ARG, "null argument");
+    const double r2 = (double)(c->cyl_r * c->cyl_r);
+    for (int y = 0; y < c->nyl; ++y)
+        for (int x = 0; x < c->nx; ++x) {
+            const double dx = x - c->cyl_x, dy = (c->p.y_start + y) - c->cyl_y;
+            mask[(size_t)y * c->nx + x] = (dx * dx + dy * dy <= r2) ? 1 : 0;
+        }
+    return LBM_OK;
+}
+
+int lbm_comm_unique_id(void* id128) {
+    if (!id128) return fail(LBM_ERR_ARG, "null argument");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    NCCLCHK(ncclGetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return LBM_OK;
+}
+
+int lbm_comm_init(lbm_ctx* c, int rank, int nranks, const void* id128) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(LBM_ERR_ARG, "bad argument");
+    if (c->initialised) return fail(LBM_ERR_ARG, "attach the communicator before lbm_initialise");
+    HIPCHK(hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
+    c->rank = rank;
+    c->nranks = nranks;
+    return LBM_OK;
+}
+
+int lbm_comm_allreduce(lbm_ctx* c, double* vals, int n, int op) {
+    if (!c || !vals || n < 1 || n > 64) return fail(LBM_ERR_ARG, "bad argument");
+    if (!c->comm) return (c->nranks == 1) ? LBM_OK : fail(LBM_ERR_COMM, "no communicator");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_red, vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const ncclRedOp_t rop = op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin);
+    NCCLCHK(ncclAllReduce(c->d_red, c->d_red, n, ncclDouble, rop, c->comm, c->stream));
+    HIPCHK(hipMemcpyAsync(vals, c->d_red, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LBM_OK;
+}
+
+int lbm_halo_export(lbm_ctx* c, double* south_out, double* north_out) {
+    if (!c || !c->initialised) return fail(LBM_ERR_ARG, "context not initialised");
+    HIPCHK(hipSetDevice(c->device));
+    return DISPATCH(c, do_halo_export<double>(c, south_out, north_out), do_halo_export<float>(c, south_out, north_out));
+}
+
+int lbm_halo_import(lbm_ctx* c, const double* south_in, const double* north_in) {
+    if (!c || !c->initialised) return fail(LBM_ERR_ARG, "context not initialised");
+    HIPCHK(hipSetDevice(c->device));
+    return DISPATCH(c, do_halo_import<double>(c, south_in, north_in), do_halo_import<float>(c, south_in, north_in));
+}
+
+int lbm_set_option(lbm_ctx* c, const char* key, long value) {
+    if (!c || !key) return fail(LBM_ERR_ARG, "null argument");
+    const std::string k(key);
+    if (k == "variant") c->variant = (int)value;
+    else if (k == "timing") c->timing = (int)value;
+    else if (k == "overlap") c->overlap = (int)value;
+    else return fail(LBM_ERR_ARG, "unknown option %s", key);
+    return LBM_OK;
+}
+
+int lbm_last_step_kernel_ms(lbm_ctx* c, double* ms_per_launch) {
+    if (!c || !ms_per_launch) return fail(LBM_ERR_ARG, "null argument");
+    *ms_per_launch = 0.0;
+    if (!c->timing || c->timed_launches <= 0) return LBM_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->ev_t1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+    *ms_per_launch = (double)ms / c->timed_launches;
+    return LBM_OK;
+}
+
+const char* lbm_kernel_name(const lbm_ctx* c) {
+    if (!c) return "";
+    return c->p.precision == LBM_PRECISION_F32 ? "k_step_site<float,0>" : "k_step_site<double,0>";
+}
+
+}  // extern "C"

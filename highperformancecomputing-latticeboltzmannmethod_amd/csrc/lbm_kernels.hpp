@@ -1,0 +1,318 @@
+// csrc/lbm_kernels.hpp — device code of the D2Q9-BGK timestep for gfx950 (CDNA4, wave64).
+//
+// One persistent state per strip: the POST-COLLISION populations P_t (the reference's f_next right after
+// collision_step() of iteration t, LBMSolver.h:84-126), stored as 9 SoA planes with a one-cell ghost frame:
+//
+//     plane i, local row gy in [0, ny_loc+2), column col in [0, pitch):   base[i*plane + gy*pitch + col]
+//     interior cell (x, y)  <->  gy = y+1, col = xoff + x       (xoff*sizeof(T) is a multiple of 128 B)
+//
+// Ghost cells hold, permanently and in BOTH A/B buffers, what the reference's halo logic leaves in them on one
+// rank: E/W ghost columns of globally-interior rows = 0, physical N/S ghost rows and the
+// four corner ghosts = the initial equilibrium; solid cells hold w_i for ever (N4). Strip-internal ghost rows
+// are refreshed every step by the halo exchange. The step kernel therefore needs no boundary branches for
+// its nine pulls and writes fluid interior cells only.
+//
+// Step kernel K_t (one launch per loop body of Solver::run, LBMSolver.h:49-60):
+//     pull from P_t        == exchange_ghost_cells + streaming_step        (LBMGrid.h:249, LBMSolver.h:128-145)
+//     wall / inlet / outlet== apply_boundary_conditions, sequential order  (LBMSolver.h:147-236)
+//     stability test       == Grid::check_stability                        (LBMGrid.h:285-317)
+//     moments + BGK        == collision_step of iteration t+1              (LBMSolver.h:84-126)
+//     store P_{t+1}
+// Algorithmic traffic: 9 loads + 9 stores per lattice update = 144 B (fp64) / 72 B (fp32). HBM-bound; no MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lbmk {
+
+constexpr int Q = 9;
+// LBMConfig.h:13-34 — direction numbering is observable through f_current(x,y,i), keep it.
+__host__ __device__ constexpr int cx(int i) { constexpr int v[Q] = {0, 1, 0, -1, 0, 1, -1, -1, 1}; return v[i]; }
+__host__ __device__ constexpr int cy(int i) { constexpr int v[Q] = {0, 0, 1, 0, -1, 1, 1, -1, -1}; return v[i]; }
+__host__ __device__ constexpr int opp(int i) { constexpr int v[Q] = {0, 3, 4, 1, 2, 7, 8, 5, 6}; return v[i]; }
+template <typename T> __host__ __device__ constexpr T wgt(int i) {
+    return i == 0 ? T(4.0 / 9.0) : (i < 5 ? T(1.0 / 9.0) : T(1.0 / 36.0));
+}
+
+template <typename T>
+struct KArgs {
+    const T* src;      // plane 0 of the buffer read  (P_t)
+    T* dst;            // plane 0 of the buffer written (P_{t+1})
+    long plane;        // elements per plane
+    int pitch;         // elements per row
+    int xoff;          // column of interior x = 0
+    int nx, ny_loc;    // interior size of this strip
+    int ny_glob;       // global rows
+    int y_start;       // global row of local y = 0
+    int cyl_x, cyl_y;  // LBMConfig.h:61-63 (integer cells)
+    double cyl_r2;     // (double)(r*r), LBMGrid.h:169
+    T tau_inv;         // 1/tau, LBMSolver.h:85
+    T u_in;            // inlet velocity
+    int* unstable_t;   // device word: first unstable iteration (INT_MAX if none)
+    int t;             // iteration this launch completes (stability bookkeeping only)
+};
+
+// Grid::setup_geometry, LBMGrid.h:152-173, as a pure function of GLOBAL integer coordinates.
+__device__ __forceinline__ bool is_solid_cell(int x, int yg, int cyl_x, int cyl_y, double cyl_r2) {
+    const double dx = (double)(x - cyl_x), dy = (double)(yg - cyl_y);
+    return dx * dx + dy * dy <= cyl_r2;
+}
+
+// apply_boundary_conditions on the pulled populations of ONE cell, in the reference's sequential loop order
+// bottom -> top -> inlet -> outlet (LBMSolver.h:152-236). Solid cells are skipped by every one
+// of those loops. Returns nothing; rho_bc/u_out are exposed for the macro snapshot kernel.
+template <typename T>
+__device__ __forceinline__ void apply_bcs(T (&f)[Q], bool bottom, bool top, bool inlet, bool outlet, T u_in,
+                                          T& rho_bc, T& u_out) {
+    if (bottom) { f[2] = f[4]; f[5] = f[7]; f[6] = f[8]; }                    // :155-163
+    if (top)    { f[4] = f[2]; f[7] = f[5]; f[8] = f[6]; }                    // :168-176
+    if (inlet) {                                                              // :181-206 (Zou-He velocity)
+        rho_bc = (f[0] + f[2] + f[4] + T(2.0) * (f[3] + f[6] + f[7])) / (T(1.0) - u_in);
+        f[1] = f[3] + T(2.0 / 3.0) * rho_bc * u_in;
+        f[5] = f[7] - T(0.5) * (f[2] - f[4]) + T(1.0 / 6.0) * rho_bc * u_in;
+        f[8] = f[6] + T(0.5) * (f[2] - f[4]) + T(1.0 / 6.0) * rho_bc * u_in;
+    }
+    if (outlet) {                                                             // :212-235 (Zou-He pressure, rho=1)
+        const T rho_out = T(1.0);
+        u_out = T(-1.0) + (f[0] + f[2] + f[4] + T(2.0) * (f[1] + f[5] + f[8])) / rho_out;
+        f[3] = f[1] - T(2.0 / 3.0) * rho_out * u_out;
+        f[6] = f[8] - T(0.5) * (f[2] - f[4]) - T(1.0 / 6.0) * rho_out * u_out;
+        f[7] = f[5] + T(0.5) * (f[2] - f[4]) - T(1.0 / 6.0) * rho_out * u_out;
+    }
+}
+
+// collision_step for one cell, LBMSolver.h:101-123 (moments i = 0..8 ascending from 0, N7).
+template <typename T>
+__device__ __forceinline__ void bgk_collide(T (&f)[Q], T tau_inv) {
+    T rho = T(0), ux = T(0), uy = T(0);
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        rho += f[i];
+        if (cx(i) != 0) ux += T(cx(i)) * f[i];
+        if (cy(i) != 0) uy += T(cy(i)) * f[i];
+    }
+    ux /= rho;
+    uy /= rho;
+    const T usq = ux * ux + uy * uy;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        const T cu = T(cx(i)) * ux + T(cy(i)) * uy;
+        const T feq = wgt<T>(i) * rho * (T(1.0) + T(3.0) * cu + T(4.5) * cu * cu - T(1.5) * usq);
+        f[i] = f[i] - tau_inv * (f[i] - feq);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ bool any_unstable(const T (&f)[Q]) {
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) bad |= !(fabs((double)f[i]) <= 1e5);   // NaN, Inf, > 1e5, < -1e5 (LBMGrid.h:296-307)
+    return bad;
+}
+
+enum StepMode { MODE_STEP = 0, MODE_COLLIDE_ONLY = 1, MODE_STREAM_ONLY = 2 };
+
+// Baseline hot kernel: one thread per lattice site, block = 256 sites of one row (4 waves), 8-byte (fp64) /
+// 4-byte (fp32) coalesced plane accesses; the x±1 pulls are the same coalesced stream shifted by one element.
+//   MODE_STEP         : K_t as described at the top of this file.
+//   MODE_COLLIDE_ONLY : collision_step of iteration 0 on the initial state (no pull, no BC, no stability test).
+//   MODE_STREAM_ONLY  : f_current snapshot for the accessor: pull + BCs + cylinder reversal
+//                       (LBMSolver.h:240-257), every interior cell written, no collision.
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) k_step_site(const KArgs<T> a) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= a.nx) return;
+    const int yg = a.y_start + y;
+    const long c = (long)(y + 1) * a.pitch + a.xoff + x;
+    T f[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        const long off = (MODE == MODE_COLLIDE_ONLY) ? 0 : (long)cy(i) * a.pitch + cx(i);
+        f[i] = a.src[(long)i * a.plane + c - off];
+    }
+    const bool solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+    if (MODE != MODE_COLLIDE_ONLY) {
+        T rho_bc, u_out;
+        if (!solid)
+            apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+    }
+    if (MODE == MODE_STEP) {
+        if (any_unstable(f)) atomicMin(a.unstable_t, a.t);
+    }
+    if (MODE == MODE_STREAM_ONLY) {
+        if (solid) {
+            T r[Q];
+#pragma unroll
+            for (int i = 0; i < Q; ++i) r[i] = f[opp(i)];
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = r[i];
+        }
+    } else {
+        if (solid) return;   // collision skips solid cells: they keep w_i for ever (LBMSolver.h:92, N4)
+        bgk_collide(f, a.tau_inv);
+    }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) a.dst[(long)i * a.plane + c] = f[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Initialisation: Grid::initialise (LBMGrid.h:185-246) written into BOTH buffers, plus the permanent ghost
+// values of N1/N2 (see top of file). feq_in = f_eq(1,(u_in,0)) evaluated on the host in double with the
+// reference's bracket order (LBMUtils.h:9-12,46); solid cells get f_eq(1,0,0) = w_i.
+template <typename T>
+struct InitArgs {
+    T* a; T* b;
+    long plane; int pitch, xoff, nx, ny_loc, ny_glob, y_start;
+    int cyl_x, cyl_y; double cyl_r2;
+    T feq_in[Q];
+    int* solid_count;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_init(const InitArgs<T> p) {
+    const int gx = blockIdx.x * 256 + threadIdx.x;   // 0 .. nx+1  (ghost-inclusive column)
+    const int gy = blockIdx.y;                       // 0 .. ny_loc+1
+    if (gx > p.nx + 1) return;
+    const int x = gx - 1, yg = p.y_start + gy - 1;   // global coordinates (may be -1 / nx / ny)
+    const bool row_interior = (yg >= 0 && yg < p.ny_glob);
+    const bool col_interior = (x >= 0 && x < p.nx);
+    const bool own_row = (gy >= 1 && gy <= p.ny_loc);
+    bool solid = false;
+    if (row_interior && col_interior) solid = is_solid_cell(x, yg, p.cyl_x, p.cyl_y, p.cyl_r2);
+    if (solid && own_row) atomicAdd(p.solid_count, 1);
+    const long c = (long)gy * p.pitch + p.xoff + x;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        T v = p.feq_in[i];
+        if (solid) v = wgt<T>(i);
+        if (row_interior && !col_interior) v = T(0);   // N1: E/W ghost column of a globally-interior row
+        p.a[(long)i * p.plane + c] = v;
+        p.b[(long)i * p.plane + c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Macroscopic snapshot from the buffer `old` = P_t that the last step kernel READ:
+//   fluid interior : moments of P_t at the cell. collision conserves rho and rho*u, so these equal the
+//                    pre-collision moments the reference stored at LBMSolver.h:112-114 to round-off (~1e-16).
+//   inlet/outlet   : (rho_bc, u_in, 0) / (1, u_out, 0) of apply_boundary_conditions of iteration t,
+//                    recomputed exactly as the step kernel did (pull from P_t + wall BC + Zou-He).
+//   solid          : (1, 0, 0) (rho never rewritten after init, u zeroed at LBMSolver.h:260-261).
+template <typename T>
+struct MacroArgs {
+    const T* old; long plane; int pitch, xoff, nx, ny_loc, ny_glob, y_start;
+    int cyl_x, cyl_y; double cyl_r2; T u_in;
+    int initial;        // steps_done == 0: analytic initial macros (LBMGrid.h:219-228)
+    double* rho; double* ux; double* uy;   // [ny_loc][nx]
+    unsigned long long* max_usq_bits;      // optional running max of ux^2+uy^2 (bit pattern of a double >= 0)
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_macros(const MacroArgs<T> p) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    double usq = 0.0;
+    if (x < p.nx) {
+        const int yg = p.y_start + y;
+        const long c = (long)(y + 1) * p.pitch + p.xoff + x;
+        const bool solid = is_solid_cell(x, yg, p.cyl_x, p.cyl_y, p.cyl_r2);
+        double r, vx, vy;
+        if (solid) { r = 1.0; vx = 0.0; vy = 0.0; }
+        else if (p.initial) { r = 1.0; vx = (double)p.u_in; vy = 0.0; }
+        else if (x == 0 || x == p.nx - 1) {
+            T f[Q];
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = p.old[(long)i * p.plane + c - (long)cy(i) * p.pitch - cx(i)];
+            T rho_bc = T(1), u_out = T(0);
+            apply_bcs(f, yg == 0, yg == p.ny_glob - 1, x == 0, x == p.nx - 1, p.u_in, rho_bc, u_out);
+            // the outlet loop runs after the inlet loop (only matters for nx == 1)
+            if (x == p.nx - 1) { r = 1.0; vx = (double)u_out; vy = 0.0; }
+            else { r = (double)rho_bc; vx = (double)p.u_in; vy = 0.0; }
+        } else {
+            T rr = T(0), sx = T(0), sy = T(0);
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                const T v = p.old[(long)i * p.plane + c];
+                rr += v;
+                if (cx(i) != 0) sx += T(cx(i)) * v;
+                if (cy(i) != 0) sy += T(cy(i)) * v;
+            }
+            sx /= rr; sy /= rr;
+            r = (double)rr; vx = (double)sx; vy = (double)sy;
+        }
+        const long m = (long)y * p.nx + x;
+        p.rho[m] = r; p.ux[m] = vx; p.uy[m] = vy;
+        usq = vx * vx + vy * vy;
+    }
+    if (p.max_usq_bits) {
+        // wave max, then one atomic per wave; non-negative doubles order like their bit patterns
+        for (int o = 32; o > 0; o >>= 1) usq = fmax(usq, __shfl_xor(usq, o));
+        if ((threadIdx.x & 63) == 0) atomicMax(p.max_usq_bits, (unsigned long long)__double_as_longlong(usq));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// IOManager::record_forces, LBMIO.h:133-160: momentum exchange over solid->fluid links, evaluated on the
+// post-collision populations P_t. One block scans the cylinder's bounding box (+1 cell) restricted to the rows
+// this strip owns, visiting FLUID cells and their solid neighbours (mask from global coordinates), so strip
+// partial sums add up to the one-rank value. Deterministic tree reduction in LDS.
+template <typename T>
+struct ForceArgs {
+    const T* cur; long plane; int pitch, xoff, nx, ny_loc, ny_glob, y_start;
+    int cyl_x, cyl_y, cyl_r; double cyl_r2;
+    int x0, x1, y0, y1;     // inclusive box in (x, local y)
+    double* out;            // out[0] = t (as double), out[1] = fx, out[2] = fy
+    int t;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(1024) k_forces(const ForceArgs<T> p) {
+    __shared__ double sfx[1024];
+    __shared__ double sfy[1024];
+    double fx = 0.0, fy = 0.0;
+    const int bw = p.x1 - p.x0 + 1, bh = p.y1 - p.y0 + 1;
+    const long ncell = (bw > 0 && bh > 0) ? (long)bw * bh : 0;
+    for (long k = threadIdx.x; k < ncell; k += 1024) {
+        const int x = p.x0 + (int)(k % bw), y = p.y0 + (int)(k / bw);
+        const int yg = p.y_start + y;
+        if (is_solid_cell(x, yg, p.cyl_x, p.cyl_y, p.cyl_r2)) continue;
+        const long c = (long)(y + 1) * p.pitch + p.xoff + x;
+#pragma unroll
+        for (int i = 1; i < Q; ++i) {
+            const int sx = x + cx(i), sy = yg + cy(i);
+            if (sx < 0 || sx >= p.nx || sy < 0 || sy >= p.ny_glob) continue;
+            if (!is_solid_cell(sx, sy, p.cyl_x, p.cyl_y, p.cyl_r2)) continue;
+            const double fi = (double)p.cur[(long)i * p.plane + c];
+            fx += 2.0 * cx(i) * fi;
+            fy += 2.0 * cy(i) * fi;
+        }
+    }
+    sfx[threadIdx.x] = fx; sfy[threadIdx.x] = fy;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sfx[threadIdx.x] += sfx[threadIdx.x + s]; sfy[threadIdx.x] += sfy[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { p.out[0] = (double)p.t; p.out[1] = sfx[0]; p.out[2] = sfy[0]; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Host-staged halo rows (lbm_halo_export / lbm_halo_import): 3 planes x nx elements per face, as double.
+template <typename T>
+__global__ void __launch_bounds__(256) k_halo_pack(const T* buf, long plane, long row_off, int nx, int i0, int i1,
+                                                   int i2, double* out) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= nx) return;
+    const int ids[3] = {i0, i1, i2};
+    for (int k = 0; k < 3; ++k) out[(long)k * nx + x] = (double)buf[(long)ids[k] * plane + row_off + x];
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_halo_unpack(T* buf, long plane, long row_off, int nx, int i0, int i1, int i2,
+                                                     const double* in) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= nx) return;
+    const int ids[3] = {i0, i1, i2};
+    for (int k = 0; k < 3; ++k) buf[(long)ids[k] * plane + row_off + x] = (T)in[(long)k * nx + x];
+}
+
+}  // namespace lbmk

@@ -1,0 +1,128 @@
+/* include/lbm_hip.h — C-ABI of the MI355X-native D2Q9-BGK timestep (liblbm_hip.so).
+ *
+ * The reference (LGMOak/HighPerformanceComputing-LatticeBoltzmannMethod) has no FFI/plugin seam: it is a
+ * header-only C++ class library driven by src/main.cpp:11-20. The seam below is therefore the set of calls
+ * the reference's own classes make on the hot path, one entry point per reference member, so that
+ * LBM::Solver / LBM::Grid / LBM::IOManager can be re-hosted on it (see INTEGRATION.md and the C++ mirror in
+ * highperformancecomputing-latticeboltzmannmethod_amd/host/). Plain C types only; all output buffers are
+ * caller-owned host memory; all device memory is owned by the context; no exceptions cross the boundary.
+ *
+ * Return convention: 0 = ok; LBM_ERR_* (<0) = failure, text via lbm_last_error(). There is NO CPU fallback:
+ * without a usable HIP device every entry point that touches state fails with LBM_ERR_HIP.
+ *
+ * Time convention: a context has completed `steps_done` loop bodies of Solver::run (LBMSolver.h:48-76).
+ * The device holds the post-collision populations of loop body t = steps_done (the reference's f_next right
+ * after collision_step() of iteration t) and those of iteration t-1, so
+ *   lbm_get_forces          == IOManager::record_forces(t = steps_done, ...)      (LBMIO.h:114-168)
+ *   lbm_get_macros          == rho/ux/uy as left by iteration steps_done-1         
+ *   lbm_get_populations     == f_current / f_next as left by iteration steps_done-1
+ */
+#ifndef LBM_HIP_H
+#define LBM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBM_OK            0
+#define LBM_ERR_ARG      -1   /* bad argument / bad state */
+#define LBM_ERR_HIP      -2   /* HIP runtime error or no device */
+#define LBM_ERR_COMM     -3   /* RCCL error / communicator not initialised */
+#define LBM_ERR_ALLOC    -4
+
+#define LBM_PRECISION_F64 0
+#define LBM_PRECISION_F32 1   /* build-only variant; the reference has no fp32 path */
+
+/* Physics: field-for-field LBM::SimulationParams (LBMConfig.h:36-51) minus the run-control fields, which
+ * stay with the host-side Solver. Strip: the row strip [y_start, y_start+local_ny) of the global ny rows this
+ * context owns (replaces Grid::initialise_2d_topology, LBMGrid.h:347-364; whole domain: y_start=0,
+ * local_ny=ny). */
+typedef struct lbm_params {
+    double tau;              /* LBMConfig.h:37 */
+    double inlet_velocity;   /* LBMConfig.h:38 */
+    int    nx, ny;           /* LBMConfig.h:39-40, global interior size */
+    double cylinder_x;       /* LBMConfig.h:46, fraction of nx */
+    double cylinder_y;       /* LBMConfig.h:47, fraction of ny */
+    double cylinder_radius;  /* LBMConfig.h:48, fraction of ny */
+    int    y_start;          /* first global row of this strip */
+    int    local_ny;         /* rows in this strip (0 => ny - y_start) */
+    int    precision;        /* LBM_PRECISION_* */
+    int    force_log_capacity; /* rows of the device-resident force log (0 => 4096) */
+} lbm_params;
+
+typedef struct lbm_ctx lbm_ctx;
+
+typedef struct lbm_force_row { int timestep; double fx, fy; } lbm_force_row;
+
+const char* lbm_last_error(void);
+int  lbm_device_count(void);
+
+/* Grid::Grid (LBMGrid.h:57-90): allocates the SoA population planes (2 buffers), macro scratch, logs. */
+int  lbm_create(const lbm_params* p, int device, lbm_ctx** out);
+void lbm_destroy(lbm_ctx* c);
+
+/* Grid::setup_geometry + Grid::initialise (LBMGrid.h:152-246) followed by collision_step() of iteration 0
+ * (LBMSolver.h:84-126). *solid_count_out (nullable) = solid cells in this strip (LBMGrid.h:158-175). */
+int  lbm_initialise(lbm_ctx* c, int* solid_count_out);
+
+/* `nsteps` loop bodies of Solver::run (LBMSolver.h:49-60): exchange + stream + BCs + stability of iteration
+ * t, fused with collision_step() of iteration t+1, one kernel launch per step. Asynchronous on the context's
+ * stream. If output_frequency > 0, record_forces is evaluated on-device for every t % output_frequency == 0
+ * inside the range (LBMSolver.h:52-54) and appended to the force log. With a communicator attached
+ * (lbm_comm_init) each step also exchanges the strip's edge rows (replaces Grid::exchange_ghost_cells,
+ * LBMGrid.h:249-283). */
+int  lbm_step(lbm_ctx* c, int nsteps, int output_frequency);
+
+int  lbm_sync(lbm_ctx* c);
+int  lbm_steps_done(const lbm_ctx* c);
+
+/* Grid::check_stability (LBMGrid.h:285-317), evaluated inside every step kernel; returns the first
+ * iteration t whose post-BC populations were non-finite or outside [-1e5, 1e5] (the t the reference prints at
+ * LBMSolver.h:62), or -1. Synchronises. */
+int  lbm_first_unstable_step(lbm_ctx* c, int* t_out);
+
+/* IOManager::record_forces (LBMIO.h:133-168) for t = steps_done: this strip's partial sums. Synchronises. */
+int  lbm_get_forces(lbm_ctx* c, double* fx, double* fy);
+/* Rows appended by lbm_step (this strip's partial sums); returns the number copied, clears the log. */
+int  lbm_drain_force_log(lbm_ctx* c, lbm_force_row* rows, int max_rows);
+
+/* rho/ux/uy of this strip, row-major [local_ny][nx] (LBMGrid.h:109-111; the layout gathered at
+ * LBMSolver.h:340-357). Any pointer may be NULL. Synchronises. */
+int  lbm_get_macros(lbm_ctx* c, double* rho, double* ux, double* uy);
+/* Grid::max_velocity (LBMGrid.h:319-344) before the cross-rank MAX and sqrt: max(ux^2+uy^2) of this strip. */
+int  lbm_max_velocity_sq(lbm_ctx* c, double* out);
+
+/* Debug/parity accessor: ghost-inclusive AoS [(local_ny+2)][(nx+2)][9] exactly as Grid::f_current /
+ * Grid::f_next index it (LBMGrid.h:105-107,116-119). which: 0 = f_current, 1 = f_next. */
+int  lbm_get_populations(lbm_ctx* c, int which, double* aos);
+/* Grid::is_solid (LBMGrid.h:146-148) for this strip, [local_ny][nx] bytes. */
+int  lbm_get_solid(lbm_ctx* c, unsigned char* mask);
+
+/* ---- strip halo exchange (replaces Grid::exchange_ghost_cells, LBMGrid.h:249-283) ----
+ * Device path: RCCL send/recv of the 3 populations per face that the pull actually consumes, on a side
+ * stream, overlapped with the interior update. `unique_id` is the 128-byte ncclUniqueId produced by
+ * lbm_comm_unique_id on rank 0 and distributed by the launcher. Ranks are ordered bottom (0) to top. */
+int  lbm_comm_unique_id(void* id128);
+int  lbm_comm_init(lbm_ctx* c, int rank, int nranks, const void* id128);
+/* Sum the partial force sums / max / min across strips (the reference's MPI_Reduce/MPI_Allreduce at
+ * LBMIO.h:167-168, LBMGrid.h:315,342). In place, host values, n doubles. op: 0 sum, 1 max, 2 min. */
+int  lbm_comm_allreduce(lbm_ctx* c, double* vals, int n, int op);
+/* Host-staged path (the buffers the reference hands to MPI_Isend/Irecv, reduced to the consumed planes):
+ * export: south_out = populations {4,7,8} of the bottom interior row, north_out = {2,5,6} of the top interior
+ * row, each [3][nx]; import: south_in = {2,5,6} for the south ghost row, north_in = {4,7,8} for the north
+ * ghost row. NULL = that side is a physical wall. Used by MPI-hosted callers and by the 2-rank tests. */
+int  lbm_halo_export(lbm_ctx* c, double* south_out, double* north_out);
+int  lbm_halo_import(lbm_ctx* c, const double* south_in, const double* north_in);
+/* With host-staged exchange the caller drives one step at a time: lbm_step(c,1,of) then export/import. */
+
+/* Tuning/diagnostics (not part of the reference surface). */
+int  lbm_set_option(lbm_ctx* c, const char* key, long value);
+/* Average device time per step-kernel launch (ms) measured with HIP events on the context's stream around
+ * the last lbm_step call; 0 if events were not enabled via lbm_set_option(c, "timing", 1). */
+int  lbm_last_step_kernel_ms(lbm_ctx* c, double* ms_per_launch);
+const char* lbm_kernel_name(const lbm_ctx* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
