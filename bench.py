@@ -34,34 +34,34 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 BYTES_PER_LUP = {"f64": 144, "f32": 72}   # 9 loads + 9 stores per lattice update
 
 
-def host_cores():
-    try:
-        return len(os.sched_getaffinity(0))
-    except AttributeError:
-        return os.cpu_count() or 1
+from oracle.oracle import host_cores  # cpu_baseline leg only (test infrastructure)
+
+
+def _time_reference(ref, d, nx, ny, u_in, steps, threads):
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="true", OMP_PLACES="cores")
+    out = subprocess.run([ref, "--nx", str(nx), "--ny", str(ny), "--steps", str(steps), "--of", "1000000",
+                          "--tau", "0.6", "--u", repr(u_in), "--time"], cwd=d, env=env, timeout=300,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    m = re.search(r"REFTIME .*threads=(\d+) seconds=([\d.]+) mlups=([\d.]+) ok=1", out.stdout)
+    if not m:
+        raise RuntimeError((out.stderr or out.stdout)[-300:])
+    return float(m.group(3))
 
 
 def cpu_baseline(nx, ny, u_in, budget_s=12.0):
     """Reported baseline only: the reference's CPU path on this host's cores, bounded sample of the same grid."""
     cores = host_cores()
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="true")
     if os.path.exists(ref):
         try:
             import tempfile
             d = tempfile.mkdtemp(prefix="lbmref_")
-            best = None
-            for steps in (5, None):
-                if steps is None:
-                    steps = max(5, min(400, int(budget_s * best * 1e6 / (nx * ny)))) if best else 20
-                out = subprocess.run([ref, "--nx", str(nx), "--ny", str(ny), "--steps", str(steps), "--of", "1000000",
-                                      "--tau", "0.6", "--u", repr(u_in), "--time"], cwd=d, env=env, timeout=300,
-                                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-                m = re.search(r"REFTIME .*threads=(\d+) seconds=([\d.]+) mlups=([\d.]+) ok=1", out.stdout)
-                if not m:
-                    raise RuntimeError(out.stderr[-300:])
-                best = float(m.group(3))
-                threads = int(m.group(1))
+            # the box exposes more hardware threads than its CPU share: probe a few thread counts, keep the best
+            cand = sorted({c for c in (8, 16, 32, 64, cores) if c <= cores})
+            probe = {c: _time_reference(ref, d, nx, ny, u_in, 3, c) for c in cand}
+            threads = max(probe, key=probe.get)
+            steps = max(5, min(400, int(budget_s * probe[threads] * 1e6 / (nx * ny))))
+            best = _time_reference(ref, d, nx, ny, u_in, steps, threads)
             return {"value": round(best, 2), "unit": "MLUPS", "cores": threads, "kind": "reference",
                     "sample": f"unmodified reference (oracle/_ref/ref_driver, -O3 -ffast-math -mavx2 -mfma -fopenmp), "
                               f"{nx}x{ny} fp64, {steps} steps incl. its per-step stability scan, 1 MPI rank x {threads} OpenMP threads"}

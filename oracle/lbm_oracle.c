@@ -41,6 +41,7 @@ int lbmo_cylinder_x_cells(const lbmo_params* p) { return (int)(p->cylinder_x * p
 int lbmo_cylinder_y_cells(const lbmo_params* p) { return (int)(p->cylinder_y * p->ny); }
 int lbmo_cylinder_radius_cells(const lbmo_params* p) { return (int)(p->cylinder_radius * p->ny); }
 int lbmo_threads(void) { return omp_get_max_threads(); }
+void lbmo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 static inline size_t fidx(const lbmo* s, int gx, int gy) { return ((size_t)gy * s->tnx + gx) * Q; }
 static inline size_t midx(const lbmo* s, int x, int y) { return (size_t)y * s->nx + x; }

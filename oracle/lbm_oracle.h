@@ -53,6 +53,7 @@ double*        lbmo_f_current(lbmo* s);
 double*        lbmo_f_next(lbmo* s);
 unsigned char* lbmo_solid(lbmo* s);
 int            lbmo_threads(void);
+void           lbmo_set_threads(int n);
 
 /* derived parameters, LBMConfig.h:54-65 */
 double lbmo_nu(const lbmo_params* p);

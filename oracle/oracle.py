@@ -29,12 +29,32 @@ def build(force=False):
 _lib = None
 
 
+def host_cores():
+    """Usable host threads: scheduler affinity clipped by a cgroup CPU quota (the GPU box exposes 256 hardware
+    threads but grants a 16-CPU share; an OpenMP team larger than the quota spins instead of computing)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+    except Exception:
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = C.CDLL(LIB_PATH)
+        L.lbmo_set_threads.restype = None; L.lbmo_set_threads.argtypes = [C.c_int]
+        if "OMP_NUM_THREADS" not in os.environ:
+            L.lbmo_set_threads(host_cores())
         dp = C.POINTER(C.c_double)
         L.lbmo_create.restype = C.c_void_p
         L.lbmo_create.argtypes = [C.POINTER(Params), C.c_int, C.c_int]
