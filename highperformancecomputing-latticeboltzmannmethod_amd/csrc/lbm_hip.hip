@@ -70,7 +70,8 @@ struct lbm_ctx {
     double feq_in[Q];
     int cyl_x = 0, cyl_y = 0, cyl_r = 0;
     // options
-    int variant = 0;
+    int variant = 0;     // 0 auto (k_step_vec when nx % V == 0), 1 force k_step_site
+    int alternate = 1;   // walk the rows bottom-up / top-down on alternate steps (Infinity Cache reuse)
     int timing = 0;
     int overlap = 1;
     int timed_launches = 0;
@@ -103,22 +104,41 @@ KArgs<T> make_kargs(const lbm_ctx* c, int src, int dst, int t) {
     a.u_in = (T)c->p.inlet_velocity;
     a.unstable_t = c->d_unstable;
     a.t = t;
+    a.y_lo = 0;
+    a.y_cnt = c->nyl;
+    a.reverse = 0;
     return a;
 }
 
-// Launch one step-family kernel over rows [y0, y0+ny) of the strip.
+template <typename T> constexpr int vec_width() { return (int)(16 / sizeof(T)); }
+
+// true: the 16-byte-per-lane kernel k_step_vec runs; false: the generic one-site-per-thread k_step_site
+inline bool use_vec(const lbm_ctx* c) {
+    const int v = (int)(16 / c->esize);
+    if (c->variant == 1) return false;
+    return c->nx % v == 0;
+}
+
+// Launch one step-family kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt).
 template <typename T, int MODE>
-void launch_site(const lbm_ctx* c, KArgs<T> a, hipStream_t s) {
-    dim3 grid((c->nx + 255) / 256, c->nyl), block(256);
-    hipLaunchKernelGGL((k_step_site<T, MODE>), grid, block, 0, s, a);
+void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
+    constexpr int V = vec_width<T>();
+    if (use_vec(c)) {
+        dim3 grid((c->nx / V + 255) / 256, a.y_cnt), block(256);
+        hipLaunchKernelGGL((k_step_vec<T, V, MODE>), grid, block, 0, s, a);
+    } else {
+        dim3 grid((c->nx + 255) / 256, a.y_cnt), block(256);
+        hipLaunchKernelGGL((k_step_site<T, MODE>), grid, block, 0, s, a);
+    }
 }
 
 template <typename T>
 int launch_step(lbm_ctx* c, int src, int dst, int t, int mode, hipStream_t s) {
     KArgs<T> a = make_kargs<T>(c, src, dst, t);
+    a.reverse = (mode == MODE_STEP && c->alternate && (t & 1)) ? 1 : 0;
     switch (mode) {
-        case MODE_STEP: launch_site<T, MODE_STEP>(c, a, s); break;
-        case MODE_COLLIDE_ONLY: launch_site<T, MODE_COLLIDE_ONLY>(c, a, s); break;
+        case MODE_STEP: launch_rows<T, MODE_STEP>(c, a, s); break;
+        case MODE_COLLIDE_ONLY: launch_rows<T, MODE_COLLIDE_ONLY>(c, a, s); break;
         default: break;
     }
     HIPCHK(hipGetLastError());
@@ -252,10 +272,10 @@ int do_populations(lbm_ctx* c, int which, double* aos) {
     const void* srcbuf = c->buf[c->cur ^ 1];
     const bool initial = (c->steps_done == 0);
     if (which == 0 && !initial) {
-        if (!c->scratch) HIPCHK(hipMalloc(&c->scratch, Q * c->plane * c->esize));
+        if (!c->scratch) HIPCHK(hipMalloc(&c->scratch, Q * c->plane * c->esize + 256));
         KArgs<T> a = make_kargs<T>(c, c->cur ^ 1, c->cur ^ 1, 0);
         a.dst = static_cast<T*>(c->scratch);
-        launch_site<T, MODE_STREAM_ONLY>(c, a, c->stream);
+        launch_rows<T, MODE_STREAM_ONLY>(c, a, c->stream);
         HIPCHK(hipGetLastError());
         srcbuf = c->scratch;
     }
@@ -352,7 +372,13 @@ int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
     const int per128 = (int)(128 / c->esize);
     c->xoff = per128;                                      // interior x=0 starts a 128-byte line
     c->pitch = round_up(c->xoff + c->nx + 1, per128);      // ghost column x=nx fits, rows stay 128-B aligned
-    c->plane = (size_t)c->pitch * (c->nyl + 2);
+    {   // Plane stride: whole rows, then rounded up to k * 64 KiB + 4 KiB. Nine planes whose stride is a multiple
+        // of 64 KiB put the nine accesses of a wave on the same HBM channel group (measured at 4096x1024 fp64:
+        // 5.2-5.4 TB/s at +0 vs 5.9-6.1 TB/s at +1..8 KiB); the +4 KiB residue spreads them.
+        const size_t raw = (size_t)c->pitch * (c->nyl + 2) * c->esize;
+        const size_t w = 65536;
+        c->plane = ((raw + w - 1) / w * w + 4096) / c->esize;
+    }
     // LBMConfig.h:61-65: truncation toward zero
     c->cyl_x = (int)(p->cylinder_x * p->nx);
     c->cyl_y = (int)(p->cylinder_y * p->ny);
@@ -381,7 +407,7 @@ int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
     HIPTRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
     HIPTRY(hipEventCreate(&c->ev_t0));
     HIPTRY(hipEventCreate(&c->ev_t1));
-    const size_t bytes = Q * c->plane * c->esize;
+    const size_t bytes = Q * c->plane * c->esize + 256;   // slack: the displaced vector load of the last row
     HIPTRY(hipMalloc(&c->buf[0], bytes));
     HIPTRY(hipMalloc(&c->buf[1], bytes));
     HIPTRY(hipMalloc(&c->d_unstable, sizeof(int)));
@@ -581,6 +607,7 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     const std::string k(key);
     if (k == "variant") c->variant = (int)value;
     else if (k == "timing") c->timing = (int)value;
+    else if (k == "alternate") c->alternate = (int)value;
     else if (k == "overlap") c->overlap = (int)value;
     else return fail(LBM_ERR_ARG, "unknown option %s", key);
     return LBM_OK;
@@ -600,7 +627,9 @@ int lbm_last_step_kernel_ms(lbm_ctx* c, double* ms_per_launch) {
 
 const char* lbm_kernel_name(const lbm_ctx* c) {
     if (!c) return "";
-    return c->p.precision == LBM_PRECISION_F32 ? "k_step_site<float,0>" : "k_step_site<double,0>";
+    const bool f32 = c->p.precision == LBM_PRECISION_F32;
+    if (use_vec(c)) return f32 ? "k_step_vec<float,4,0>" : "k_step_vec<double,2,0>";
+    return f32 ? "k_step_site<float,0>" : "k_step_site<double,0>";
 }
 
 }  // extern "C"
