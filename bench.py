@@ -177,7 +177,7 @@ def main():
                                    f"u_in={u_in:.8f} (BASELINE.json configs[2])",
                        "nx": nx, "ny": ny_total, "rows_per_gpu": local_ny, "decomposition": f"{world} row strip(s)",
                        "halo": "none" if world == 1 else "RCCL send/recv, 3 populations x 1 row per face",
-                       "kernel": ctx.kernel_name()},
+                       "kernel": ctx.kernel_name(), "plan": ctx.plan()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": ctx.kernel_name(), "kernel_ms": round(kernel_ms, 5),

@@ -63,6 +63,7 @@ def lib():
         L.lbm_set_option.argtypes = [vp, C.c_char_p, C.c_long]
         L.lbm_last_step_kernel_ms.argtypes = [vp, dp]
         L.lbm_kernel_name.argtypes = [vp]; L.lbm_kernel_name.restype = C.c_char_p
+        L.lbm_plan.argtypes = [vp]; L.lbm_plan.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -79,7 +80,8 @@ class Context:
     """One strip of the lattice on one GPU (struct lbm_ctx)."""
 
     def __init__(self, nx, ny, tau=0.6, inlet_velocity=0.01333, cylinder_x=0.2, cylinder_y=0.5,
-                 cylinder_radius=0.05, y_start=0, local_ny=0, precision="f64", device=0, force_log_capacity=0):
+                 cylinder_radius=0.05, y_start=0, local_ny=0, precision="f64", device=0, force_log_capacity=0,
+                 options=None):
         self.L = lib()
         self.params = Params(tau, inlet_velocity, nx, ny, cylinder_x, cylinder_y, cylinder_radius, y_start,
                              local_ny, {"f64": 0, "f32": 1}[precision], force_log_capacity)
@@ -89,6 +91,8 @@ class Context:
         self.h = C.c_void_p()
         self._chk(self.L.lbm_create(C.byref(self.params), device, C.byref(self.h)))
         self.solid_count = None
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
 
     def _chk(self, rc):
         if rc < 0:
@@ -201,3 +205,6 @@ class Context:
 
     def kernel_name(self):
         return self.L.lbm_kernel_name(self.h).decode()
+
+    def plan(self):
+        return self.L.lbm_plan(self.h).decode()

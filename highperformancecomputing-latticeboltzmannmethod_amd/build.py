@@ -21,7 +21,9 @@ def build_all(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h"))]
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "lbm_hip.h"))
     if force or _newer(LIB, srcs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared",
+        # -ffp-contract=off: no fused multiply-add is formed behind the source's back, so every formulation of the
+        # step kernel (site / vector, any layout) and the strict-IEEE oracle evaluate the same operation sequence
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", "-shared",
                "-o", LIB, os.path.join(CSRC, "lbm_hip.hip"),
                "-L" + os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
         if verbose:

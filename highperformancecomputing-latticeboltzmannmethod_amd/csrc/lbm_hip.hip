@@ -52,8 +52,12 @@ struct lbm_ctx {
     hipStream_t stream = nullptr;       // compute stream (all kernels)
     hipStream_t comm_stream = nullptr;  // halo exchange (RCCL send/recv)
     hipEvent_t ev_edge = nullptr, ev_comm = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
-    int nx = 0, nyl = 0, pitch = 0, xoff = 0;
-    size_t plane = 0;        // elements per plane
+    int nx = 0, nyl = 0, xoff = 0;
+    int pitch0 = 0;          // elements of one sub-row (ghost columns + 128-B padding included)
+    int pitch = 0;           // ROW stride: elements between consecutive rows of one plane
+    size_t plane = 0;        // PLANE stride: elements between the same cell of consecutive planes
+    size_t total = 0;        // elements per population buffer
+    int layout = 0;          // 0 planar, 1 row-interleaved (see lbm_kernels.hpp)
     size_t esize = 8;        // bytes per element
     void* buf[2] = {nullptr, nullptr};
     int cur = 0;             // buf[cur] = P_{steps_done}; buf[cur^1] = P_{steps_done-1} (or the initial state)
@@ -70,8 +74,11 @@ struct lbm_ctx {
     double feq_in[Q];
     int cyl_x = 0, cyl_y = 0, cyl_r = 0;
     // options
-    int variant = 0;     // 0 auto (k_step_vec when nx % V == 0), 1 force k_step_site
+    int variant = 0;     // 0: k_step_vec when nx % V == 0; 1: k_step_site
     int alternate = 1;   // walk the rows bottom-up / top-down on alternate steps (Infinity Cache reuse)
+    int use_nt = 0;      // non-temporal stores in the step kernel
+    int tune = 1;        // lbm_initialise times the candidate plans on this device and keeps the fastest
+    char plan_desc[160] = "";
     int timing = 0;
     int overlap = 1;
     int timed_launches = 0;
@@ -119,16 +126,38 @@ inline bool use_vec(const lbm_ctx* c) {
     return c->nx % v == 0;
 }
 
+// Strides of the two layouts. Planar: plane stride = whole rows rounded up to k*64 KiB + 4 KiB (nine planes whose
+// stride is a multiple of 64 KiB put the nine accesses of a wave on the same HBM channel group: 5.2-5.4 TB/s at +0
+// vs 5.9-6.1 TB/s at +1..8 KiB, 4096x1024 fp64). Row-interleaved: the nine sub-rows of a lattice row are adjacent.
+inline void configure_layout(lbm_ctx* c, int layout) {
+    c->layout = layout;
+    if (layout == 1) {
+        c->plane = (size_t)c->pitch0;
+        c->pitch = Q * c->pitch0;
+        c->total = (size_t)c->pitch * (c->nyl + 2);
+    } else {
+        const size_t raw = (size_t)c->pitch0 * (c->nyl + 2) * c->esize;
+        const size_t w = 65536;
+        c->plane = ((raw + w - 1) / w * w + 4096) / c->esize;
+        c->pitch = c->pitch0;
+        c->total = (size_t)Q * c->plane;
+    }
+}
+inline size_t buffer_bytes(const lbm_ctx* c) { return c->total * c->esize + 256; }  // +slack: displaced vector load
+
 // Launch one step-family kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt).
 template <typename T, int MODE>
 void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
     constexpr int V = vec_width<T>();
+    const bool nt = (MODE == MODE_STEP) && c->use_nt;
     if (use_vec(c)) {
         dim3 grid((c->nx / V + 255) / 256, a.y_cnt), block(256);
-        hipLaunchKernelGGL((k_step_vec<T, V, MODE>), grid, block, 0, s, a);
+        if (nt) hipLaunchKernelGGL((k_step_vec<T, V, MODE, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_step_vec<T, V, MODE, false>), grid, block, 0, s, a);
     } else {
         dim3 grid((c->nx + 255) / 256, a.y_cnt), block(256);
-        hipLaunchKernelGGL((k_step_site<T, MODE>), grid, block, 0, s, a);
+        if (nt) hipLaunchKernelGGL((k_step_site<T, MODE, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_step_site<T, MODE, false>), grid, block, 0, s, a);
     }
 }
 
@@ -194,7 +223,7 @@ int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
 }
 
 template <typename T>
-int do_initialise(lbm_ctx* c) {
+int init_state(lbm_ctx* c) {
     InitArgs<T> ia;
     ia.a = static_cast<T*>(c->buf[0]);
     ia.b = static_cast<T*>(c->buf[1]);
@@ -211,6 +240,120 @@ int do_initialise(lbm_ctx* c) {
     int rc = launch_step<T>(c, 0, 1, 0, MODE_COLLIDE_ONLY, c->stream);
     if (rc) return rc;
     c->cur = 1;
+    c->steps_done = 0;
+    return LBM_OK;
+}
+
+inline void free_buffers(lbm_ctx* c) {
+    for (int k = 0; k < 2; ++k)
+        if (c->buf[k]) { (void)hipFree(c->buf[k]); c->buf[k] = nullptr; }
+}
+inline int alloc_buffers(lbm_ctx* c) {
+    free_buffers(c);
+    HIPCHK(hipMalloc(&c->buf[0], buffer_bytes(c)));
+    HIPCHK(hipMalloc(&c->buf[1], buffer_bytes(c)));
+    return LBM_OK;
+}
+
+// ---- plan: pick layout / kernel / store policy / traversal by measurement --------------------------------
+// The step is a pure 18-stream copy with arithmetic attached; which formulation the memory system likes best
+// depends on the grid (working set vs the 256 MiB Infinity Cache, row length vs channel interleave) and even on
+// where the allocation landed physically (measured: the same planar plan runs at 100 us or 110 us per step at
+// 4096x1024 fp64 depending on the allocation). All candidates compute bit-identical results, so lbm_initialise
+// times each one on the real buffers (8 warm-up + 24 timed launches, a few ms) and keeps the fastest together
+// with the very allocation it was measured on.
+struct Plan { int layout, variant, nt, alternate; const char* name; };
+
+template <typename T>
+int time_plan(lbm_ctx* c, float* ms_out) {
+    int rc = init_state<T>(c);
+    if (rc) return rc;
+    auto run = [&](int n) -> int {
+        for (int k = 0; k < n; ++k) {
+            const int t = c->steps_done, dst = c->cur ^ 1;
+            int r = launch_step<T>(c, c->cur, dst, t, MODE_STEP, c->stream);
+            if (r) return r;
+            c->cur = dst;
+            c->steps_done = t + 1;
+        }
+        return LBM_OK;
+    };
+    rc = run(8);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_t0, c->stream));
+    rc = run(24);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_t1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev_t1));
+    HIPCHK(hipEventElapsedTime(ms_out, c->ev_t0, c->ev_t1));
+    *ms_out /= 24.f;
+    return LBM_OK;
+}
+
+template <typename T>
+int choose_plan(lbm_ctx* c) {
+    const Plan fixed = {c->layout, c->variant, c->use_nt, c->alternate, "fixed by options"};
+    std::vector<Plan> cand;
+    const bool vec_ok = (c->nx % vec_width<T>() == 0);
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    configure_layout(c, 1);
+    const size_t need = 2 * buffer_bytes(c);
+    // tiny grids are launch/latency bound (nothing to choose); huge ones cannot afford a second live allocation
+    const bool can_tune = c->tune && (size_t)c->nx * c->nyl >= (1u << 20) && 2 * need + (1u << 28) < free_b;
+    if (!c->tune) cand.push_back(fixed);
+    else if (!can_tune) cand.push_back({0, vec_ok ? 0 : 1, 0, 1, "planar/alternate (default, not measured)"});
+    else {
+        if (vec_ok) cand.push_back({0, 0, 0, 1, "planar/vec16B/alternate"});
+        cand.push_back({1, 1, 1, 0, "row-interleaved/site/nt-store"});
+        cand.push_back({1, 1, 0, 1, "row-interleaved/site/alternate"});
+        if (vec_ok) cand.push_back({1, 0, 1, 0, "row-interleaved/vec16B/nt-store"});
+        if (vec_ok) cand.push_back({1, 0, 0, 0, "row-interleaved/vec16B"});
+        cand.push_back({0, 1, 0, 1, "planar/site/alternate"});
+        if (vec_ok) cand.push_back({0, 0, 0, 1, "planar/vec16B/alternate (2nd allocation)"});
+    }
+    void* best_buf[2] = {nullptr, nullptr};
+    float best_ms = 1e30f;
+    int best = -1;
+    std::string log;
+    for (size_t k = 0; k < cand.size(); ++k) {
+        const Plan& pl = cand[k];
+        configure_layout(c, pl.layout);
+        c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate;
+        c->buf[0] = c->buf[1] = nullptr;            // keep the best allocation alive while the next one is probed
+        int rc = alloc_buffers(c);
+        if (rc) { c->buf[0] = best_buf[0]; c->buf[1] = best_buf[1]; return rc; }
+        float ms = 0.f;
+        if (cand.size() > 1) {
+            rc = time_plan<T>(c, &ms);
+            if (rc) return rc;
+        }
+        if (ms < best_ms) {
+            for (void* q : best_buf) if (q) (void)hipFree(q);
+            best_buf[0] = c->buf[0]; best_buf[1] = c->buf[1];
+            best_ms = ms; best = (int)k;
+        } else {
+            free_buffers(c);
+        }
+    }
+    const Plan& pl = cand[best];
+    configure_layout(c, pl.layout);
+    c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate;
+    c->buf[0] = best_buf[0]; c->buf[1] = best_buf[1];
+    if (cand.size() > 1) snprintf(c->plan_desc, sizeof(c->plan_desc), "%s (fastest of %zu measured, %.1f us/step)", pl.name,
+                                  cand.size(), best_ms * 1e3f);
+    else snprintf(c->plan_desc, sizeof(c->plan_desc), "%s", pl.name);
+    return LBM_OK;
+}
+
+template <typename T>
+int do_initialise(lbm_ctx* c) {
+    int rc = choose_plan<T>(c);
+    if (rc) return rc;
+    const int big = INT_MAX;
+    HIPCHK(hipMemcpyAsync(c->d_unstable, &big, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    rc = init_state<T>(c);
+    if (rc) return rc;
     if (c->comm) {
         rc = exchange_rccl<T>(c, c->cur, c->stream);
         if (rc) return rc;
@@ -272,15 +415,15 @@ int do_populations(lbm_ctx* c, int which, double* aos) {
     const void* srcbuf = c->buf[c->cur ^ 1];
     const bool initial = (c->steps_done == 0);
     if (which == 0 && !initial) {
-        if (!c->scratch) HIPCHK(hipMalloc(&c->scratch, Q * c->plane * c->esize + 256));
+        if (!c->scratch) HIPCHK(hipMalloc(&c->scratch, buffer_bytes(c)));
         KArgs<T> a = make_kargs<T>(c, c->cur ^ 1, c->cur ^ 1, 0);
         a.dst = static_cast<T*>(c->scratch);
         launch_rows<T, MODE_STREAM_ONLY>(c, a, c->stream);
         HIPCHK(hipGetLastError());
         srcbuf = c->scratch;
     }
-    std::vector<T> host(Q * c->plane);
-    HIPCHK(hipMemcpyAsync(host.data(), srcbuf, Q * c->plane * c->esize, hipMemcpyDeviceToHost, c->stream));
+    std::vector<T> host(c->total);
+    HIPCHK(hipMemcpyAsync(host.data(), srcbuf, c->total * c->esize, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int gy = 0; gy < tny; ++gy)
         for (int gx = 0; gx < tnx; ++gx) {
@@ -371,14 +514,8 @@ int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
     c->esize = p->precision == LBM_PRECISION_F32 ? 4 : 8;
     const int per128 = (int)(128 / c->esize);
     c->xoff = per128;                                      // interior x=0 starts a 128-byte line
-    c->pitch = round_up(c->xoff + c->nx + 1, per128);      // ghost column x=nx fits, rows stay 128-B aligned
-    {   // Plane stride: whole rows, then rounded up to k * 64 KiB + 4 KiB. Nine planes whose stride is a multiple
-        // of 64 KiB put the nine accesses of a wave on the same HBM channel group (measured at 4096x1024 fp64:
-        // 5.2-5.4 TB/s at +0 vs 5.9-6.1 TB/s at +1..8 KiB); the +4 KiB residue spreads them.
-        const size_t raw = (size_t)c->pitch * (c->nyl + 2) * c->esize;
-        const size_t w = 65536;
-        c->plane = ((raw + w - 1) / w * w + 4096) / c->esize;
-    }
+    c->pitch0 = round_up(c->xoff + c->nx + 1, per128);     // ghost column x=nx fits, rows stay 128-B aligned
+    configure_layout(c, 0);
     // LBMConfig.h:61-65: truncation toward zero
     c->cyl_x = (int)(p->cylinder_x * p->nx);
     c->cyl_y = (int)(p->cylinder_y * p->ny);
@@ -407,9 +544,7 @@ int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
     HIPTRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
     HIPTRY(hipEventCreate(&c->ev_t0));
     HIPTRY(hipEventCreate(&c->ev_t1));
-    const size_t bytes = Q * c->plane * c->esize + 256;   // slack: the displaced vector load of the last row
-    HIPTRY(hipMalloc(&c->buf[0], bytes));
-    HIPTRY(hipMalloc(&c->buf[1], bytes));
+    // the population buffers are allocated by lbm_initialise (the plan decides their layout)
     HIPTRY(hipMalloc(&c->d_unstable, sizeof(int)));
     HIPTRY(hipMalloc(&c->d_solid_count, sizeof(int)));
     HIPTRY(hipMalloc(&c->d_maxbits, sizeof(unsigned long long)));
@@ -443,11 +578,9 @@ void lbm_destroy(lbm_ctx* c) {
 int lbm_initialise(lbm_ctx* c, int* solid_count_out) {
     if (!c) return fail(LBM_ERR_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
-    const int big = INT_MAX;
-    HIPCHK(hipMemcpyAsync(c->d_unstable, &big, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
     c->steps_done = 0;
     c->log_count = 0;
+    if (c->scratch) { (void)hipFree(c->scratch); c->scratch = nullptr; }
     int rc = DISPATCH(c, do_initialise<double>(c), do_initialise<float>(c));
     if (rc) return rc;
     int sc = 0;
@@ -605,9 +738,14 @@ int lbm_halo_import(lbm_ctx* c, const double* south_in, const double* north_in) 
 int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     if (!c || !key) return fail(LBM_ERR_ARG, "null argument");
     const std::string k(key);
+    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune"))
+        return fail(LBM_ERR_ARG, "option %s must be set before lbm_initialise", key);
     if (k == "variant") c->variant = (int)value;
     else if (k == "timing") c->timing = (int)value;
     else if (k == "alternate") c->alternate = (int)value;
+    else if (k == "layout") c->layout = (int)value ? 1 : 0;
+    else if (k == "nt") c->use_nt = (int)value ? 1 : 0;
+    else if (k == "tune") c->tune = (int)value ? 1 : 0;
     else if (k == "overlap") c->overlap = (int)value;
     else return fail(LBM_ERR_ARG, "unknown option %s", key);
     return LBM_OK;
@@ -628,8 +766,12 @@ int lbm_last_step_kernel_ms(lbm_ctx* c, double* ms_per_launch) {
 const char* lbm_kernel_name(const lbm_ctx* c) {
     if (!c) return "";
     const bool f32 = c->p.precision == LBM_PRECISION_F32;
-    if (use_vec(c)) return f32 ? "k_step_vec<float,4,0>" : "k_step_vec<double,2,0>";
-    return f32 ? "k_step_site<float,0>" : "k_step_site<double,0>";
+    if (use_vec(c)) return f32 ? (c->use_nt ? "k_step_vec<float,4,0,true>" : "k_step_vec<float,4,0,false>")
+                               : (c->use_nt ? "k_step_vec<double,2,0,true>" : "k_step_vec<double,2,0,false>");
+    return f32 ? (c->use_nt ? "k_step_site<float,0,true>" : "k_step_site<float,0,false>")
+               : (c->use_nt ? "k_step_site<double,0,true>" : "k_step_site<double,0,false>");
 }
+
+const char* lbm_plan(const lbm_ctx* c) { return c ? c->plan_desc : ""; }
 
 }  // extern "C"

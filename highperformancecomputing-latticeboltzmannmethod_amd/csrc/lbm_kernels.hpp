@@ -3,8 +3,13 @@
 // One persistent state per strip: the POST-COLLISION populations P_t (the reference's f_next right after
 // collision_step() of iteration t, LBMSolver.h:84-126), stored as 9 SoA planes with a one-cell ghost frame:
 //
-//     plane i, local row gy in [0, ny_loc+2), column col in [0, pitch):   base[i*plane + gy*pitch + col]
+//     plane i, local row gy in [0, ny_loc+2), column col:   base[i*plane + gy*pitch + col]
 //     interior cell (x, y)  <->  gy = y+1, col = xoff + x       (xoff*sizeof(T) is a multiple of 128 B)
+// The two strides describe either of two layouts chosen by the host (lbm_hip.hip, "plan"):
+//     PLANAR          plane = rows*pitch0 (+pad), pitch = pitch0            nine separate planes
+//     ROW-INTERLEAVED plane = pitch0,             pitch = 9*pitch0          [gy][i][col]: the nine sub-rows of a
+//                     lattice row are adjacent, so a block's 18 streams stay inside two ~300 KB windows
+// Every kernel below is layout-agnostic: it only uses (plane, pitch).
 //
 // Ghost cells hold, permanently and in BOTH A/B buffers, what the reference's halo logic leaves in them on one
 // rank: E/W ghost columns of globally-interior rows = 0, physical N/S ghost rows and the
@@ -127,7 +132,7 @@ enum StepMode { MODE_STEP = 0, MODE_COLLIDE_ONLY = 1, MODE_STREAM_ONLY = 2 };
 //   MODE_COLLIDE_ONLY : collision_step of iteration 0 on the initial state (no pull, no BC, no stability test).
 //   MODE_STREAM_ONLY  : f_current snapshot for the accessor: pull + BCs + cylinder reversal
 //                       (LBMSolver.h:240-257), every interior cell written, no collision.
-template <typename T, int MODE>
+template <typename T, int MODE, bool NT = false>
 __global__ void __launch_bounds__(256) k_step_site(const KArgs<T> a) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = row_of_block(a);
@@ -162,7 +167,11 @@ __global__ void __launch_bounds__(256) k_step_site(const KArgs<T> a) {
         bgk_collide(f, a.tau_inv);
     }
 #pragma unroll
-    for (int i = 0; i < Q; ++i) a.dst[(long)i * a.plane + c] = f[i];
+    for (int i = 0; i < Q; ++i) {
+        T* p = a.dst + (long)i * a.plane + c;
+        if (NT) __builtin_nontemporal_store(f[i], p);   // streaming store: do not keep the line in L2
+        else *p = f[i];
+    }
 }
 
 // Production hot kernel: V = 16 B / sizeof(T) consecutive sites per thread (2 fp64 / 4 fp32), so every plane
@@ -171,7 +180,7 @@ __global__ void __launch_bounds__(256) k_step_site(const KArgs<T> a) {
 // (element-aligned dwordx4; the displaced wave touches 9 instead of 8 128-B lines, the extra one is shared with
 // its neighbour through L2). Requires nx % V == 0; other widths use k_step_site. Solid sites inside a vector are
 // rewritten with w_i, which is what they hold already (N4), so the stores stay full-width.
-template <typename T, int V, int MODE>
+template <typename T, int V, int MODE, bool NT = false>
 __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
     typedef T VA __attribute__((ext_vector_type(V)));                       // naturally aligned vector
     typedef T VU __attribute__((ext_vector_type(V), aligned(sizeof(T))));   // element-aligned vector
@@ -227,7 +236,11 @@ __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
         if (bad) atomicMin(a.unstable_t, a.t);
     }
 #pragma unroll
-    for (int i = 0; i < Q; ++i) *reinterpret_cast<VA*>(a.dst + (long)i * a.plane + c) = fv[i];
+    for (int i = 0; i < Q; ++i) {
+        VA* p = reinterpret_cast<VA*>(a.dst + (long)i * a.plane + c);
+        if (NT) __builtin_nontemporal_store(fv[i], p);
+        else *p = fv[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

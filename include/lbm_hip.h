@@ -115,12 +115,18 @@ int  lbm_halo_export(lbm_ctx* c, double* south_out, double* north_out);
 int  lbm_halo_import(lbm_ctx* c, const double* south_in, const double* north_in);
 /* With host-staged exchange the caller drives one step at a time: lbm_step(c,1,of) then export/import. */
 
-/* Tuning/diagnostics (not part of the reference surface). */
+/* Tuning/diagnostics (not part of the reference surface). Keys, all to be set before lbm_initialise:
+ *   "tune" 1|0    time the candidate plans at lbm_initialise and keep the fastest (default 1); with 0 the plan is
+ *                 "layout" 0 planar|1 row-interleaved, "variant" 0 16-B-per-lane kernel|1 one site per thread,
+ *                 "nt" non-temporal stores, "alternate" alternate the row walk direction per step
+ *   "timing" 1    record HIP events around each lbm_step call (lbm_last_step_kernel_ms). */
 int  lbm_set_option(lbm_ctx* c, const char* key, long value);
 /* Average device time per step-kernel launch (ms) measured with HIP events on the context's stream around
  * the last lbm_step call; 0 if events were not enabled via lbm_set_option(c, "timing", 1). */
 int  lbm_last_step_kernel_ms(lbm_ctx* c, double* ms_per_launch);
 const char* lbm_kernel_name(const lbm_ctx* c);
+/* The plan lbm_initialise settled on (layout / kernel / store policy / traversal), for logs. */
+const char* lbm_plan(const lbm_ctx* c);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,8 @@ __global__ void __launch_bounds__(256) k_site_vec(const KArgs<T> a) {
 
 static long g_boff = 0;
 static bool g_single = false;
+static bool g_leak = false;
+static int g_trials = 1;
 // ---- harness ---------------------------------------------------------------------------------------------
 template <typename T>
 struct Bench {
@@ -134,7 +136,7 @@ struct Bench {
             total = (size_t)Q * plane;
         }
         pitch = rowstride;
-        if (g_single) { CK(hipMalloc(&A, (2 * total + 65536) * sizeof(T))); B = A + total + g_boff / sizeof(T); }
+        if (g_single) { CK(hipMalloc(&A, (2 * total + 64) * sizeof(T) + g_boff)); B = A + total + g_boff / sizeof(T); }
         else { CK(hipMalloc(&A, (total + 64) * sizeof(T))); CK(hipMalloc(&B, (total + 64) * sizeof(T))); }
         printf("A=%p B=%p\n", (void*)A, (void*)B);
         CK(hipMalloc(&d_unst, sizeof(int)));
@@ -142,10 +144,11 @@ struct Bench {
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         u_in = 200.0 * (0.1 / 3.0) / (0.1 * ny);
     }
-    ~Bench() { hipFree(A); if (!g_single) hipFree(B); hipFree(d_unst); hipStreamDestroy(s); hipEventDestroy(e0); hipEventDestroy(e1); }
+    ~Bench() { if (!g_leak) { hipFree(A); if (!g_single) hipFree(B); } hipFree(d_unst); hipStreamDestroy(s); hipEventDestroy(e0); hipEventDestroy(e1); }
 
     KArgs<T> args(bool flip) {
-        KArgs<T> a;
+        KArgs<T> a{};
+        a.y_lo = 0; a.y_cnt = ny; a.reverse = 0;
         a.src = flip ? B : A; a.dst = flip ? A : B;
         a.plane = plane; a.pitch = pitch; a.xoff = xoff; a.nx = nx; a.ny_loc = ny; a.ny_glob = ny; a.y_start = 0;
         a.cyl_x = (int)(0.2 * nx); a.cyl_y = (int)(0.5 * ny);
@@ -241,9 +244,12 @@ int main(int argc, char** argv) {
         else if (k == "--variants") g_filter = argv[++i];
         else if (k == "--boff") g_boff = atol(argv[++i]);
         else if (k == "--single") g_single = true;
+        else if (k == "--leak") g_leak = true;
+        else if (k == "--trials") g_trials = atoi(argv[++i]);
         else if (k == "--pitchpads") { ppads.clear(); char* tok = strtok(argv[++i], ","); while (tok) { ppads.push_back(atol(tok)); tok = strtok(nullptr, ","); } }
         else if (k == "--pads") { pads.clear(); char* tok = strtok(argv[++i], ","); while (tok) { pads.push_back(atol(tok)); tok = strtok(nullptr, ","); } }
     }
+    for (int tr = 0; tr < g_trials; ++tr)
     for (long pp : ppads)
         for (long pad : pads) {
             if (prec == "f64") suite<double>(nx, ny, pad, reps, rounds, rowil, (int)pp);
