@@ -8,3 +8,4 @@ numerics of its own and fails loudly if the HIP library is missing.
 """
 from .binding import (LbmError, Params, Context, lib, lib_path, device_count)  # noqa: F401
 from .build import build_all  # noqa: F401
+from .strips import partition_rows, GlooHalo  # noqa: F401

@@ -85,6 +85,7 @@ struct lbm_ctx {
     // communicator
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    bool comm_issued = false;   // ev_comm has been recorded at least once
     double* d_red = nullptr;
     // host-staged halo staging (device side)
     double* d_halo = nullptr;  // 4 x 3 x nx doubles
@@ -219,6 +220,57 @@ int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
         }
     }
     NCCLCHK(ncclGroupEnd());
+    return LBM_OK;
+}
+
+// One step of a strip that has neighbours: the edge rows first, so that their send can start while
+// the interior rows are still being updated.
+//   compute stream : wait(ev_comm of step t-1) -> edge rows -> record(ev_edge) -> interior rows
+//   comm stream    : wait(ev_edge) -> ncclSend/ncclRecv group -> record(ev_comm)
+// Hazards covered by those two events: edge(t) reads the ghost rows recv(t-1) wrote; recv(t) overwrites ghost rows
+// of the buffer edge(t-1) read (ordered through ev_edge(t) on the comm stream); send(t) reads what edge(t) wrote;
+// edge(t+1) overwrites rows send(t-1) read (ordered through ev_comm(t)). Interior rows touch neither ghost rows
+// nor (for writing) edge rows.
+template <typename T>
+int step_with_exchange(lbm_ctx* c, int src, int dst, int t) {
+    KArgs<T> a = make_kargs<T>(c, src, dst, t);
+    const bool has_s = c->rank > 0, has_n = c->rank + 1 < c->nranks;
+    if (!c->overlap) {
+        int rc = launch_step<T>(c, src, dst, t, MODE_STEP, c->stream);
+        if (rc) return rc;
+        return exchange_rccl<T>(c, dst, c->stream);
+    }
+    if (c->comm_issued) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+    int lo = 0, hi = c->nyl;
+    if (has_s) {
+        a.y_lo = 0; a.y_cnt = 1; a.reverse = 0;
+        launch_rows<T, MODE_STEP>(c, a, c->stream);
+        lo = 1;
+    }
+    if (has_n && (c->nyl > 1 || !has_s)) {
+        a.y_lo = c->nyl - 1; a.y_cnt = 1; a.reverse = 0;
+        launch_rows<T, MODE_STEP>(c, a, c->stream);
+        hi = c->nyl - 1;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev_edge, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_edge, 0));
+    int rc = exchange_rccl<T>(c, dst, c->comm_stream);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
+    c->comm_issued = true;
+    if (hi > lo) {
+        a.y_lo = lo; a.y_cnt = hi - lo;
+        a.reverse = (c->alternate && (t & 1)) ? 1 : 0;
+        launch_rows<T, MODE_STEP>(c, a, c->stream);
+        HIPCHK(hipGetLastError());
+    }
+    return LBM_OK;
+}
+
+// Make everything issued so far (both streams) visible to work queued on the compute stream afterwards.
+inline int join_comm(lbm_ctx* c) {
+    if (c->comm_issued) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     return LBM_OK;
 }
 
@@ -373,12 +425,9 @@ int do_steps(lbm_ctx* c, int nsteps, int of) {
             c->log_count++;
         }
         const int src = c->cur, dst = c->cur ^ 1;
-        int rc = launch_step<T>(c, src, dst, t, MODE_STEP, c->stream);
+        int rc = (c->comm && c->nranks > 1) ? step_with_exchange<T>(c, src, dst, t)
+                                            : launch_step<T>(c, src, dst, t, MODE_STEP, c->stream);
         if (rc) return rc;
-        if (c->comm) {
-            rc = exchange_rccl<T>(c, dst, c->stream);
-            if (rc) return rc;
-        }
         c->cur = dst;
         c->steps_done = t + 1;
     }
@@ -602,6 +651,7 @@ int lbm_sync(lbm_ctx* c) {
     if (!c) return fail(LBM_ERR_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->comm_stream));
     return LBM_OK;
 }
 
@@ -620,6 +670,7 @@ int lbm_first_unstable_step(lbm_ctx* c, int* t_out) {
 int lbm_get_forces(lbm_ctx* c, double* fx, double* fy) {
     if (!c || !c->initialised) return fail(LBM_ERR_ARG, "context not initialised");
     HIPCHK(hipSetDevice(c->device));
+    { int jr = join_comm(c); if (jr) return jr; }
     int rc = DISPATCH(c, launch_forces<double>(c, c->d_force_now, c->steps_done),
                       launch_forces<float>(c, c->d_force_now, c->steps_done));
     if (rc) return rc;
@@ -651,6 +702,7 @@ int lbm_drain_force_log(lbm_ctx* c, lbm_force_row* rows, int max_rows) {
 int lbm_get_macros(lbm_ctx* c, double* rho, double* ux, double* uy) {
     if (!c || !c->initialised) return fail(LBM_ERR_ARG, "context not initialised");
     HIPCHK(hipSetDevice(c->device));
+    { int jr = join_comm(c); if (jr) return jr; }
     int rc = DISPATCH(c, do_macros<double>(c, false), do_macros<float>(c, false));
     if (rc) return rc;
     const size_t n = (size_t)c->nx * c->nyl;
@@ -664,6 +716,7 @@ int lbm_get_macros(lbm_ctx* c, double* rho, double* ux, double* uy) {
 int lbm_max_velocity_sq(lbm_ctx* c, double* out) {
     if (!c || !c->initialised || !out) return fail(LBM_ERR_ARG, "bad argument");
     HIPCHK(hipSetDevice(c->device));
+    { int jr = join_comm(c); if (jr) return jr; }
     int rc = DISPATCH(c, do_macros<double>(c, true), do_macros<float>(c, true));
     if (rc) return rc;
     unsigned long long bits = 0;
@@ -676,6 +729,7 @@ int lbm_max_velocity_sq(lbm_ctx* c, double* out) {
 int lbm_get_populations(lbm_ctx* c, int which, double* aos) {
     if (!c || !c->initialised || !aos || (which != 0 && which != 1)) return fail(LBM_ERR_ARG, "bad argument");
     HIPCHK(hipSetDevice(c->device));
+    { int jr = join_comm(c); if (jr) return jr; }
     return DISPATCH(c, do_populations<double>(c, which, aos), do_populations<float>(c, which, aos));
 }
 
@@ -726,12 +780,14 @@ int lbm_comm_allreduce(lbm_ctx* c, double* vals, int n, int op) {
 int lbm_halo_export(lbm_ctx* c, double* south_out, double* north_out) {
     if (!c || !c->initialised) return fail(LBM_ERR_ARG, "context not initialised");
     HIPCHK(hipSetDevice(c->device));
+    { int jr = join_comm(c); if (jr) return jr; }
     return DISPATCH(c, do_halo_export<double>(c, south_out, north_out), do_halo_export<float>(c, south_out, north_out));
 }
 
 int lbm_halo_import(lbm_ctx* c, const double* south_in, const double* north_in) {
     if (!c || !c->initialised) return fail(LBM_ERR_ARG, "context not initialised");
     HIPCHK(hipSetDevice(c->device));
+    { int jr = join_comm(c); if (jr) return jr; }
     return DISPATCH(c, do_halo_import<double>(c, south_in, north_in), do_halo_import<float>(c, south_in, north_in));
 }
 
