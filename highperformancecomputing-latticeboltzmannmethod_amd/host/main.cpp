@@ -1,0 +1,72 @@
+// host/main.cpp — lbm_solver: the reference's driver sequence (src/main.cpp:11-20: params -> Solver -> IOManager ->
+// initialise -> run -> write_final_results) on the MI355X backend, plus what the reference lacks: command-line
+// overrides for every SimulationParams field and backend options.
+#include "compat/LBMConfig.h"
+#include "compat/LBMIO.h"
+#include "compat/LBMSolver.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <string>
+
+static void usage() {
+    std::puts("lbm_solver [--nx N] [--ny N] [--steps N] [--output-frequency N] [--tau X] [--inlet-velocity X]\n"
+              "           [--reynolds RE] [--cylinder-x F] [--cylinder-y F] [--cylinder-radius F] [--vtk-start-step N]\n"
+              "           [--no-vtk] [--no-final] [--sync-vtk] [--fp32] [--no-tune] [--device D] [--quiet]\n"
+              "Defaults are the reference's SimulationParams (LBMConfig.h:37-51). --reynolds sets the inlet velocity\n"
+              "from tau and the cylinder diameter so that params.reynolds() equals RE.");
+}
+
+int main(int argc, char** argv) {
+    LBM::SimulationParams params;
+    LBM::BackendOptions opt;
+    bool vtk = true, final_results = true;
+    double reynolds = -1.0;
+    for (int a = 1; a < argc; ++a) {
+        const std::string k = argv[a];
+        auto val = [&]() -> const char* {
+            if (a + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", k.c_str()); std::exit(2); }
+            return argv[++a];
+        };
+        if (k == "--nx") params.nx = std::atoi(val());
+        else if (k == "--ny") params.ny = std::atoi(val());
+        else if (k == "--steps") params.num_timesteps = std::atoi(val());
+        else if (k == "--output-frequency") params.output_frequency = std::atoi(val());
+        else if (k == "--tau") params.tau = std::atof(val());
+        else if (k == "--inlet-velocity") params.inlet_velocity = std::atof(val());
+        else if (k == "--reynolds") reynolds = std::atof(val());
+        else if (k == "--cylinder-x") params.cylinder_x = std::atof(val());
+        else if (k == "--cylinder-y") params.cylinder_y = std::atof(val());
+        else if (k == "--cylinder-radius") params.cylinder_radius = std::atof(val());
+        else if (k == "--vtk-start-step") params.vtk_start_step = std::atoi(val());
+        else if (k == "--no-vtk") vtk = false;
+        else if (k == "--no-final") final_results = false;
+        else if (k == "--sync-vtk") opt.async_vtk = false;
+        else if (k == "--fp32") opt.fp32 = true;
+        else if (k == "--no-tune") opt.tune = false;
+        else if (k == "--device") opt.device = std::atoi(val());
+        else if (k == "--quiet") opt.quiet = true;
+        else if (k == "--help" || k == "-h") { usage(); return 0; }
+        else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); usage(); return 2; }
+    }
+    if (reynolds > 0.0) params.inlet_velocity = reynolds * params.nu() / (2.0 * params.cylinder_radius * params.ny);
+    try {
+        LBM::Solver solver(params, vtk, opt);
+        LBM::IOManager io_manager;
+        solver.initialise();
+        const bool success = solver.run(io_manager);
+        if (success) {
+            if (final_results) io_manager.write_final_results(solver.get_grid(), solver.get_params());
+            std::printf("\nSimulation completed successfully!\n");
+        } else {
+            std::fprintf(stderr, "LBM simulation failed.\n");
+            return 1;
+        }
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "An exception occurred: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

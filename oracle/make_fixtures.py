@@ -13,6 +13,8 @@ Fixture sets:
   g4_1024x256_re100_s3000   tau=0.6 u=0.13020833: every-4th-point rho/ux/uy, six full rows, forces every 100
   g6_inlet_cyl_64x32_s50    cylinder centred ON the inlet column (solid cells in x=0): all arrays
   g7_wall_cyl_64x32_s50     cylinder touching the bottom wall: all arrays
+  g9_files_64x32_s1201      the reference's output FILES byte for byte: forces.csv, last VTK frame, velocity_field.csv,
+                            simulation_params.csv, stdout (IOManager / write_vtk_frame, LBMIO.h, LBMSolver.h:269-362)
   g8{a,b}_unstable_128x32   tau=0.502 u=0.35 / tau=0.51 u=0.15: the timestep at which the reference reports instability
 """
 import os
@@ -30,13 +32,15 @@ FLAG = {"tau": "--tau", "inlet_velocity": "--u", "cylinder_x": "--cylx", "cylind
         "cylinder_radius": "--cylr"}
 
 
-def run_ref(nx, ny, steps, of=140, **kw):
+def run_ref(nx, ny, steps, of=140, files=False, **kw):
     d = tempfile.mkdtemp(prefix="lbmref_")
     args = [REF, "--nx", str(nx), "--ny", str(ny), "--steps", str(steps), "--of", str(of), "--dump", d + "/d.bin"]
+    if files:
+        args += ["--vtk", "--final"]
     for k, v in kw.items():
         args += [FLAG[k], repr(float(v))]
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    pr = subprocess.run(args, cwd=d, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    pr = subprocess.run(args, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     raw = open(d + "/d.bin", "rb").read()
     hdr = np.frombuffer(raw[:16], dtype=np.int32)
     off = 16
@@ -55,6 +59,14 @@ def run_ref(nx, ny, steps, of=140, **kw):
     out["forces"] = np.loadtxt(d + "/forces.csv", delimiter=",", skiprows=1, ndmin=2)
     out["forces_text"] = np.array(open(d + "/forces.csv").read())
     out["ok"] = np.array(int(hdr[3]))
+    if files:   # the reference's output FILES, byte for byte (data: expected outputs of the writers)
+        out["velocity_field_csv"] = np.frombuffer(open(d + "/velocity_field.csv", "rb").read(), dtype=np.uint8)
+        out["simulation_params_csv"] = np.frombuffer(open(d + "/simulation_params.csv", "rb").read(), dtype=np.uint8)
+        out["forces_csv"] = np.frombuffer(open(d + "/forces.csv", "rb").read(), dtype=np.uint8)
+        frames = sorted(os.listdir(d + "/vtk_output"))
+        out["vtk_names"] = np.array(frames)
+        out["vtk_last"] = np.frombuffer(open(d + "/vtk_output/" + frames[-1], "rb").read(), dtype=np.uint8)
+        out["stdout"] = np.array(pr.stdout)
     m = re.search(r"unstable at timestep (\d+)", pr.stderr)
     out["unstable_t"] = np.array(int(m.group(1)) if m else -1)
     params = dict(nx=nx, ny=ny, steps=steps, output_frequency=of, tau=0.6, inlet_velocity=0.01333,
@@ -78,6 +90,13 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     macros = {"rho", "ux", "uy", "solid", "max_velocity", "ok"}
     allk = macros | {"f_current", "f_next", "forces", "forces_text"}
+    # g9: the reference's output files (forces.csv, vtk_output/lbm_%06d.vtk, velocity_field.csv,
+    # simulation_params.csv) of a 64x32 run, 1201 steps, output every 400 (frames at t=400,800,1200)
+    d = run_ref(64, 32, 1201, of=400, files=True, inlet_velocity=0.04, cylinder_radius=0.1)
+    save("g9_files_64x32_s1201", d, macros | {"velocity_field_csv", "simulation_params_csv", "forces_csv", "vtk_names",
+                                              "vtk_last", "stdout"})
+    if "--only-g9" in sys.argv:
+        return
     for s in (1, 2, 10, 100):
         d = run_ref(128, 32, s, of=50)
         save(f"g1_128x32_s{s}", d, allk if s in (2, 100) else macros | {"forces", "forces_text"})

@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
     LBM::SimulationParams p;
     p.num_timesteps = 10;
     std::string dump;
-    bool timing = false;
+    bool timing = false, vtk = false, final_results = false;
     for (int a = 1; a < argc; ++a) {
         std::string k = argv[a];
         auto val = [&]() -> const char* { return (a + 1 < argc) ? argv[++a] : "0"; };
@@ -41,11 +41,13 @@ int main(int argc, char** argv) {
         else if (k == "--cylr") p.cylinder_radius = atof(val());
         else if (k == "--dump") dump = val();
         else if (k == "--time") timing = true;
+        else if (k == "--vtk") vtk = true;                 // Solver(params, enable_vtk = true), LBMSolver.h:23
+        else if (k == "--final") final_results = true;     // IOManager::write_final_results, LBMIO.h:194
         else { fprintf(stderr, "unknown arg %s\n", k.c_str()); return 2; }
     }
     int rc = 0;
     {
-        LBM::Solver solver(p, false);
+        LBM::Solver solver(p, vtk);
         LBM::IOManager io;
         solver.initialise();
         auto t0 = std::chrono::steady_clock::now();
@@ -59,6 +61,7 @@ int main(int argc, char** argv) {
                    (double)p.nx * p.ny * p.num_timesteps / sec / 1e6, (int)ok);
         }
         if (!ok) rc = 1;
+        if (ok && final_results) io.write_final_results(solver.get_grid(), solver.get_params());
         if (!dump.empty() && g.mpi_size() == 1) {
             FILE* fp = fopen(dump.c_str(), "wb");
             if (!fp) { perror("dump"); MPI_Finalize(); return 3; }

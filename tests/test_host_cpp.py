@@ -1,0 +1,72 @@
+"""The C++20 host mirror (host/lbm_solver = the reference's main.cpp sequence on the HIP backend): its output FILES
+against the reference's own files (tests/golden/g9_files_64x32_s1201.npz, produced by the unmodified reference).
+Text is compared line by line: headers/integers exactly, decimals to the 8 printed digits +-1e-8 (the sign of a
+value that prints as 0.00000000 may differ)."""
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests.helpers import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "highperformancecomputing-latticeboltzmannmethod_amd"
+EXE = os.path.join(ROOT, PKG, "host", "lbm_solver")
+NUM = re.compile(r"^-?\d+\.\d+$")
+
+
+def same_text(ours, ref, tol=1.5e-8):
+    lo, lr = ours.splitlines(), ref.splitlines()
+    assert len(lo) == len(lr), (len(lo), len(lr))
+    for a, b in zip(lo, lr):
+        if a == b:
+            continue
+        ta, tb = re.split(r"[ ,]", a), re.split(r"[ ,]", b)
+        assert len(ta) == len(tb), (a, b)
+        for u, v in zip(ta, tb):
+            if u == v:
+                continue
+            assert NUM.match(u) and NUM.match(v), (a, b)
+            assert abs(float(u) - float(v)) <= tol, (a, b)
+
+
+def test_host_sources_build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, PKG, "host")])
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--sync-vtk", "--no-tune"]])
+def test_lbm_solver_files_match_reference(extra):
+    g = load_golden("g9_files_64x32_s1201")
+    d = tempfile.mkdtemp(prefix="lbm_host_")
+    cmd = [EXE, "--nx", "64", "--ny", "32", "--steps", "1201", "--output-frequency", "400", "--inlet-velocity", "0.04",
+           "--cylinder-radius", "0.1"] + extra
+    pr = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    same_text(open(os.path.join(d, "forces.csv")).read(), bytes(g["forces_csv"]).decode())
+    same_text(open(os.path.join(d, "velocity_field.csv")).read(), bytes(g["velocity_field_csv"]).decode())
+    same_text(open(os.path.join(d, "simulation_params.csv")).read(), bytes(g["simulation_params_csv"]).decode())
+    assert sorted(os.listdir(os.path.join(d, "vtk_output"))) == list(g["vtk_names"])
+    same_text(open(os.path.join(d, "vtk_output", "lbm_001200.vtk")).read(), bytes(g["vtk_last"]).decode())
+    ref_lines = [l for l in str(g["stdout"]).splitlines() if l.startswith("Timestep ")]
+    our_lines = [l for l in pr.stdout.splitlines() if l.startswith("Timestep ")]
+    assert our_lines == ref_lines
+    assert "Solid cells: 29" in pr.stdout and "Simulation completed successfully!" in pr.stdout
+
+
+@pytest.mark.gpu
+def test_lbm_solver_reports_instability_like_the_reference():
+    g = load_golden("g8b_unstable_128x32")
+    d = tempfile.mkdtemp(prefix="lbm_host_")
+    cmd = [EXE, "--nx", "128", "--ny", "32", "--steps", "2000", "--output-frequency", "50", "--tau", "0.51",
+           "--inlet-velocity", "0.15", "--no-vtk", "--quiet"]
+    pr = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert pr.returncode == 1
+    assert f"Simulation unstable at timestep {int(g['unstable_t'])}" in pr.stderr
+    assert "LBM simulation failed." in pr.stderr
+    rows = open(os.path.join(d, "forces.csv")).read().splitlines()[1:]
+    assert [int(r.split(",")[0]) for r in rows] == [0, 50]      # record_forces ran at t=0 and t=50 (< 74)
