@@ -103,9 +103,81 @@ __global__ void __launch_bounds__(256) k_site_vec(const KArgs<T> a) {
     }
 }
 
+
+// ---- two timesteps per launch (temporal blocking through LDS) ---------------------------------------------------
+// A block owns a TX x TY tile of outputs at step t+2. Phase 1 computes P_{t+1} for the (TX+2) x (TY+2) region around
+// it from global P_t (pull + BCs + collide, ghost/solid cells get their permanent constants) into LDS; phase 2
+// pulls from LDS, applies BCs, collides and stores P_{t+2}. HBM traffic per LUP: ~(1 + (TX+2)(TY+2)/(TX*TY)) * 36 B.
+template <typename T> struct K2Extra { T feq_in[Q]; };
+
+template <typename T, int TY, int NTH, bool NT>
+__global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Extra<T> e) {
+    constexpr int TX = 64, RW = TX + 2, RH = TY + 2, LP = RW + 2;
+    __shared__ T lds[Q][RH][LP];
+    const int X0 = blockIdx.x * TX;
+    int by = blockIdx.y;
+    if (a.reverse) by = gridDim.y - 1 - by;
+    const int Y0 = by * TY;
+    bool bad = false;
+    // phase 1
+    for (int r = threadIdx.x; r < RW * RH; r += NTH) {
+        const int ry = r / RW, rx = r - ry * RW;
+        const int x = X0 + rx - 1, y = Y0 + ry - 1;          // local coordinates, -1 .. nx / ny_loc
+        if (y > a.ny_loc) continue;                            // below-partial last tile: nothing there
+        const int yg = a.y_start + y;
+        const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+        T f[Q];
+        if (!(row_in && col_in)) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = (row_in && !col_in) ? T(0) : e.feq_in[i];
+        } else {
+            const long c = (long)(y + 1) * a.pitch + a.xoff + x;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
+            const bool solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+            T rho_bc, u_out;
+            if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+            bad |= any_unstable(f);
+            if (solid) {
+#pragma unroll
+                for (int i = 0; i < Q; ++i) f[i] = wgt<T>(i);
+            } else bgk_collide(f, a.tau_inv);
+        }
+#pragma unroll
+        for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
+    }
+    if (bad) atomicMin(a.unstable_t, a.t);
+    __syncthreads();
+    // phase 2
+    bad = false;
+    for (int o = threadIdx.x; o < TX * TY; o += NTH) {
+        const int ly = o / TX, lx = o - ly * TX;
+        const int x = X0 + lx, y = Y0 + ly;
+        if (y >= a.ny_loc || x >= a.nx) continue;
+        const int yg = a.y_start + y;
+        T f[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) f[i] = lds[i][ly + 1 - cy(i)][lx + 1 - cx(i)];
+        const bool solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+        T rho_bc, u_out;
+        if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+        bad |= any_unstable(f);
+        if (solid) continue;
+        bgk_collide(f, a.tau_inv);
+        const long c = (long)(y + 1) * a.pitch + a.xoff + x;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            T* p = a.dst + (long)i * a.plane + c;
+            if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
+        }
+    }
+    if (bad) atomicMin(a.unstable_t, a.t + 1);
+}
+
 static long g_boff = 0;
 static bool g_single = false;
 static bool g_leak = false;
+static bool g_check = false;
 static int g_trials = 1;
 // ---- harness ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -210,6 +282,34 @@ void suite(int nx, int ny, long pad, int reps, int rounds, bool rowil, int pitch
         for (auto& v : vars) if (("," + g_filter + ",").find("," + v.name + ",") != std::string::npos) keep.push_back(v);
         vars = keep;
     }
+    {
+        K2Extra<T> ex;
+        const double ux = b.u_in, usq = ux * ux, t3 = 1.5 * usq;
+        ex.feq_in[0] = (T)(wgt<double>(0) * (1.0 - 1.5 * usq));
+        for (int i = 1; i < Q; ++i) { const double cu = cx(i) * ux; ex.feq_in[i] = (T)(wgt<double>(i) * (((1.0 + 3.0 * cu) - t3) + 4.5 * cu * cu)); }
+        auto g2 = [&](int ty) { return dim3(nx / 64, (ny + ty - 1) / ty); };
+        vars.push_back({"step2 TY8 512t", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 8, 512, false>), g2(8), dim3(512), 0, s, a, ex); }, {}});
+        vars.push_back({"step2 TY8 704t", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 8, 704, false>), g2(8), dim3(704), 0, s, a, ex); }, {}});
+        vars.push_back({"step2 TY8 512t nt", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 8, 512, true>), g2(8), dim3(512), 0, s, a, ex); }, {}});
+        vars.push_back({"step2 TY4 384t", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 4, 384, false>), g2(4), dim3(384), 0, s, a, ex); }, {}});
+        vars.push_back({"step2 TY12 768t", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 12, 768, false>), g2(12), dim3(768), 0, s, a, ex); }, {}});
+        vars.push_back({"step2 TY16 1024t", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 16, 1024, false>), g2(16), dim3(1024), 0, s, a, ex); }, {}});
+        vars.push_back({"step2 TY16 1024t nt", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 16, 1024, true>), g2(16), dim3(1024), 0, s, a, ex); }, {}});
+    }
+    if (g_check) {   // step2 variants: 6 launches must equal 12 single steps, bit for bit
+        std::vector<T> ref(b.total), got(b.total);
+        b.init();
+        for (int k = 0; k < 12; ++k) { hipLaunchKernelGGL((k_step_site<T, MODE_STEP>), grid1, dim3(256), 0, s, b.args(b.t & 1)); ++b.t; }
+        CK(hipMemcpyAsync(ref.data(), b.A, b.total * sizeof(T), hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s));
+        for (auto& v : vars) {
+            if (v.name.rfind("step2", 0) != 0) continue;
+            b.init();
+            for (int k = 0; k < 6; ++k) { KArgs<T> a = b.args(k & 1); a.t = 2 * k; v.fn(a); }
+            CK(hipMemcpyAsync(got.data(), b.A, b.total * sizeof(T), hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s));
+            size_t diff = 0; for (size_t k = 0; k < b.total; ++k) diff += (memcmp(&ref[k], &got[k], sizeof(T)) != 0);
+            printf("CHECK %-24s %s (%zu differing elements)\n", v.name.c_str(), diff ? "MISMATCH" : "bit-identical to 12 single steps", diff);
+        }
+    }
     for (int r = 0; r < rounds; ++r)
         for (auto& v : vars) {
             b.init();
@@ -220,6 +320,8 @@ void suite(int nx, int ny, long pad, int reps, int rounds, bool rowil, int pitch
            sizeof(T) == 8 ? "f64" : "f32", rowil ? "ROW-INTERLEAVED" : "PLANAR", b.pitch, b.plane, pad, pitch_pad, reps, rounds);
     for (auto& v : vars) {
         std::sort(v.ms.begin(), v.ms.end());
+        const double lup = (v.name.rfind("step2", 0) == 0) ? 2.0 : 1.0;
+        for (auto& m : v.ms) m /= lup;   // per lattice update
         const double med = v.ms[v.ms.size() / 2], mn = v.ms[0];
         printf("  %-26s median %8.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)   best %8.2f us %7.1f GB/s\n", v.name.c_str(), med * 1e3,
                bytes / med / 1e6, bytes / med / 1e6 / 80.0, mn * 1e3, bytes / mn / 1e6);
@@ -245,6 +347,7 @@ int main(int argc, char** argv) {
         else if (k == "--boff") g_boff = atol(argv[++i]);
         else if (k == "--single") g_single = true;
         else if (k == "--leak") g_leak = true;
+        else if (k == "--check") g_check = true;
         else if (k == "--trials") g_trials = atoi(argv[++i]);
         else if (k == "--pitchpads") { ppads.clear(); char* tok = strtok(argv[++i], ","); while (tok) { ppads.push_back(atol(tok)); tok = strtok(nullptr, ","); } }
         else if (k == "--pads") { pads.clear(); char* tok = strtok(argv[++i], ","); while (tok) { pads.push_back(atol(tok)); tok = strtok(nullptr, ","); } }
