@@ -62,6 +62,7 @@ def lib():
         L.lbm_halo_import.argtypes = [vp, dp, dp]
         L.lbm_set_option.argtypes = [vp, C.c_char_p, C.c_long]
         L.lbm_last_step_kernel_ms.argtypes = [vp, dp]
+        L.lbm_last_step_stats.argtypes = [vp, dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.lbm_kernel_name.argtypes = [vp]; L.lbm_kernel_name.restype = C.c_char_p
         L.lbm_plan.argtypes = [vp]; L.lbm_plan.restype = C.c_char_p
         _lib = L
@@ -187,9 +188,12 @@ class Context:
         self._chk(self.L.lbm_comm_allreduce(self.h, _dp(a), a.size, {"sum": 0, "max": 1, "min": 2}[op]))
         return a
 
+    HALO_ROWS = 2   # LBM_HALO_ROWS
+
     def halo_export(self, south=True, north=True):
-        s = np.empty((3, self.nx), dtype=np.float64) if south else None
-        n = np.empty((3, self.nx), dtype=np.float64) if north else None
+        """(south_out, north_out): my bottom / top HALO_ROWS interior rows, each [HALO_ROWS, 9, nx]."""
+        s = np.empty((self.HALO_ROWS, 9, self.nx), dtype=np.float64) if south else None
+        n = np.empty((self.HALO_ROWS, 9, self.nx), dtype=np.float64) if north else None
         self._chk(self.L.lbm_halo_export(self.h, _dp(s), _dp(n)))
         return s, n
 
@@ -197,6 +201,12 @@ class Context:
         s = np.ascontiguousarray(south, dtype=np.float64) if south is not None else None
         n = np.ascontiguousarray(north, dtype=np.float64) if north is not None else None
         self._chk(self.L.lbm_halo_import(self.h, _dp(s), _dp(n)))
+
+    def last_step_stats(self):
+        """(device ms of the last step() call, step-kernel launches it issued, iterations it advanced)."""
+        ms, nl, ni = C.c_double(), C.c_int(), C.c_int()
+        self._chk(self.L.lbm_last_step_stats(self.h, C.byref(ms), C.byref(nl), C.byref(ni)))
+        return ms.value, nl.value, ni.value
 
     def last_step_kernel_ms(self):
         v = C.c_double()

@@ -77,18 +77,23 @@ struct lbm_ctx {
     int variant = 0;     // 0: k_step_vec when nx % V == 0; 1: k_step_site
     int alternate = 1;   // walk the rows bottom-up / top-down on alternate steps (Infinity Cache reuse)
     int use_nt = 0;      // non-temporal stores in the step kernel
+    int pair = 0;        // fuse two iterations per launch (k_step2_tile) where the schedule allows
+    int pair_ty = 8;     // tile height of the two-step kernel (8 or 12)
+    int trailing_pair = 0;   // allow an lbm_step call to END on a fused launch (host-staged strips: nsteps == 2)
+    bool last_was_pair = false;
     int tune = 1;        // lbm_initialise times the candidate plans on this device and keeps the fastest
     char plan_desc[160] = "";
     int timing = 0;
     int overlap = 1;
-    int timed_launches = 0;
+    int timed_launches = 0, timed_steps = 0;
+    long launches_total = 0;
     // communicator
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     bool comm_issued = false;   // ev_comm has been recorded at least once
     double* d_red = nullptr;
     // host-staged halo staging (device side)
-    double* d_halo = nullptr;  // 4 x 3 x nx doubles
+    double* d_halo = nullptr;  // 4 faces-in-flight x [GR][9][nx] doubles
 };
 
 namespace {
@@ -135,9 +140,9 @@ inline void configure_layout(lbm_ctx* c, int layout) {
     if (layout == 1) {
         c->plane = (size_t)c->pitch0;
         c->pitch = Q * c->pitch0;
-        c->total = (size_t)c->pitch * (c->nyl + 2);
+        c->total = (size_t)c->pitch * (c->nyl + 2 * GR);
     } else {
-        const size_t raw = (size_t)c->pitch0 * (c->nyl + 2) * c->esize;
+        const size_t raw = (size_t)c->pitch0 * (c->nyl + 2 * GR) * c->esize;
         const size_t w = 65536;
         c->plane = ((raw + w - 1) / w * w + 4096) / c->esize;
         c->pitch = c->pitch0;
@@ -162,12 +167,30 @@ void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
     }
 }
 
+// The two-step kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt): iterations a.t and a.t + 1.
+template <typename T>
+void launch_pair_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
+    K2Extra<T> e;
+    for (int i = 0; i < Q; ++i) e.feq_in[i] = (T)c->feq_in[i];
+    const int ty = c->pair_ty;
+    dim3 grid(c->nx / 64, (a.y_cnt + ty - 1) / ty);
+    if (ty == 12) {
+        if (c->use_nt) hipLaunchKernelGGL((k_step2_tile<T, 12, 768, true>), grid, dim3(768), 0, s, a, e);
+        else hipLaunchKernelGGL((k_step2_tile<T, 12, 768, false>), grid, dim3(768), 0, s, a, e);
+    } else {
+        if (c->use_nt) hipLaunchKernelGGL((k_step2_tile<T, 8, 512, true>), grid, dim3(512), 0, s, a, e);
+        else hipLaunchKernelGGL((k_step2_tile<T, 8, 512, false>), grid, dim3(512), 0, s, a, e);
+    }
+}
+inline bool pair_possible(const lbm_ctx* c) { return c->nx % 64 == 0; }
+
 template <typename T>
 int launch_step(lbm_ctx* c, int src, int dst, int t, int mode, hipStream_t s) {
     KArgs<T> a = make_kargs<T>(c, src, dst, t);
-    a.reverse = (mode == MODE_STEP && c->alternate && (t & 1)) ? 1 : 0;
+    a.reverse = ((mode == MODE_STEP || mode == 100) && c->alternate && (c->launches_total & 1)) ? 1 : 0;
     switch (mode) {
         case MODE_STEP: launch_rows<T, MODE_STEP>(c, a, s); break;
+        case 100: launch_pair_rows<T>(c, a, s); break;     // two iterations: t and t+1
         case MODE_COLLIDE_ONLY: launch_rows<T, MODE_COLLIDE_ONLY>(c, a, s); break;
         default: break;
     }
@@ -193,65 +216,65 @@ int launch_forces(lbm_ctx* c, double* out, int t) {
 }
 
 // ---- halo exchange over RCCL -------------------------------------------------------------------------
-// After K_t has produced P_{t+1} in buf[dst]: my top interior row's {2,5,6} go to the north neighbour's south
-// ghost row, my bottom interior row's {4,7,8} to the south neighbour's north ghost row. In SoA
-// each is a contiguous run of nx elements, so there is no pack kernel; 3 sends + 3 recvs per face in one group.
+// After a launch has produced the new populations in buf[dst]: my top GR interior rows go to the north neighbour's
+// south ghost rows, my bottom GR interior rows to the south neighbour's north ghost rows, all nine populations
+// (the two-step kernel recomputes the neighbour's edge row, which needs every population; per lattice update this
+// is the reference's 9 values per edge cell, LBMGrid.h:404-406). Strips always use the row-interleaved layout, in
+// which GR rows x 9 sub-rows are ONE contiguous run of GR*pitch elements: one send + one recv per face, no packing.
 template <typename T>
 int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
     if (c->nranks <= 1) return LBM_OK;
+    if (c->layout != 1) return fail(LBM_ERR_COMM, "strips require the row-interleaved layout");
     T* base = static_cast<T*>(c->buf[dst]);
     const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
-    const long row_top = (long)c->nyl * c->pitch + c->xoff;        // top interior row (gy = nyl)
-    const long row_bot = (long)1 * c->pitch + c->xoff;             // bottom interior row (gy = 1)
-    const long ghost_n = (long)(c->nyl + 1) * c->pitch + c->xoff;  // north ghost row
-    const long ghost_s = (long)c->xoff;                            // south ghost row (gy = 0)
-    const int up[3] = {2, 5, 6}, down[3] = {4, 7, 8};
+    const size_t cnt = (size_t)GR * c->pitch;
+    const long top_rows = (long)c->nyl * c->pitch;            // gy = nyl .. nyl+GR-1   (interior rows nyl-GR .. nyl-1)
+    const long bot_rows = (long)GR * c->pitch;                // gy = GR .. 2GR-1        (interior rows 0 .. GR-1)
+    const long ghost_n = (long)(c->nyl + GR) * c->pitch;      // north ghost rows
+    const long ghost_s = 0;                                   // south ghost rows
     NCCLCHK(ncclGroupStart());
     if (c->rank + 1 < c->nranks) {
-        for (int k = 0; k < 3; ++k) {
-            NCCLCHK(ncclSend(base + (long)up[k] * c->plane + row_top, c->nx, dt, c->rank + 1, c->comm, s));
-            NCCLCHK(ncclRecv(base + (long)down[k] * c->plane + ghost_n, c->nx, dt, c->rank + 1, c->comm, s));
-        }
+        NCCLCHK(ncclSend(base + top_rows, cnt, dt, c->rank + 1, c->comm, s));
+        NCCLCHK(ncclRecv(base + ghost_n, cnt, dt, c->rank + 1, c->comm, s));
     }
     if (c->rank > 0) {
-        for (int k = 0; k < 3; ++k) {
-            NCCLCHK(ncclSend(base + (long)down[k] * c->plane + row_bot, c->nx, dt, c->rank - 1, c->comm, s));
-            NCCLCHK(ncclRecv(base + (long)up[k] * c->plane + ghost_s, c->nx, dt, c->rank - 1, c->comm, s));
-        }
+        NCCLCHK(ncclSend(base + bot_rows, cnt, dt, c->rank - 1, c->comm, s));
+        NCCLCHK(ncclRecv(base + ghost_s, cnt, dt, c->rank - 1, c->comm, s));
     }
     NCCLCHK(ncclGroupEnd());
     return LBM_OK;
 }
 
-// One step of a strip that has neighbours: the edge rows first, so that their send can start while
-// the interior rows are still being updated.
-//   compute stream : wait(ev_comm of step t-1) -> edge rows -> record(ev_edge) -> interior rows
+// One launch (one iteration, or two with the two-step kernel) of a strip that has neighbours: the edge
+// rows first, so that their send can start while the interior rows are still being updated.
+//   compute stream : wait(ev_comm of the previous launch) -> edge rows -> record(ev_edge) -> interior rows
 //   comm stream    : wait(ev_edge) -> ncclSend/ncclRecv group -> record(ev_comm)
-// Hazards covered by those two events: edge(t) reads the ghost rows recv(t-1) wrote; recv(t) overwrites ghost rows
-// of the buffer edge(t-1) read (ordered through ev_edge(t) on the comm stream); send(t) reads what edge(t) wrote;
-// edge(t+1) overwrites rows send(t-1) read (ordered through ev_comm(t)). Interior rows touch neither ghost rows
-// nor (for writing) edge rows.
+// Edge = the E rows next to a neighbour (E = GR for one iteration, one tile band for two), which contain the GR rows
+// that are sent. Hazards covered by the two events: edge(n) reads the ghost rows recv(n-1) wrote; recv(n) overwrites
+// ghost rows of the buffer edge(n-1) read (ordered through ev_edge(n) on the comm stream); send(n) reads what
+// edge(n) wrote; edge(n+1) overwrites rows send(n-1) read (ordered through ev_comm(n)). Interior rows read no ghost
+// row (E >= GR) and write no edge row.
 template <typename T>
-int step_with_exchange(lbm_ctx* c, int src, int dst, int t) {
+int advance_with_exchange(lbm_ctx* c, int src, int dst, int t, bool pair) {
     KArgs<T> a = make_kargs<T>(c, src, dst, t);
     const bool has_s = c->rank > 0, has_n = c->rank + 1 < c->nranks;
+    auto launch = [&](int lo, int cnt, int reverse) {
+        a.y_lo = lo; a.y_cnt = cnt; a.reverse = reverse;
+        if (pair) launch_pair_rows<T>(c, a, c->stream);
+        else launch_rows<T, MODE_STEP>(c, a, c->stream);
+    };
+    const int rev = (c->alternate && (c->launches_total & 1)) ? 1 : 0;
     if (!c->overlap) {
-        int rc = launch_step<T>(c, src, dst, t, MODE_STEP, c->stream);
-        if (rc) return rc;
+        launch(0, c->nyl, rev);
+        HIPCHK(hipGetLastError());
         return exchange_rccl<T>(c, dst, c->stream);
     }
     if (c->comm_issued) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
-    int lo = 0, hi = c->nyl;
-    if (has_s) {
-        a.y_lo = 0; a.y_cnt = 1; a.reverse = 0;
-        launch_rows<T, MODE_STEP>(c, a, c->stream);
-        lo = 1;
-    }
-    if (has_n && (c->nyl > 1 || !has_s)) {
-        a.y_lo = c->nyl - 1; a.y_cnt = 1; a.reverse = 0;
-        launch_rows<T, MODE_STEP>(c, a, c->stream);
-        hi = c->nyl - 1;
-    }
+    const int E = pair ? c->pair_ty : GR;
+    int e0 = has_s ? E : 0, e1 = has_n ? E : 0;
+    if (e0 + e1 >= c->nyl) { e0 = c->nyl; e1 = 0; }          // short strip: everything is edge
+    if (e0 > 0) launch(0, e0, 0);
+    if (e1 > 0) launch(c->nyl - e1, e1, 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_edge, c->stream));
     HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_edge, 0));
@@ -259,13 +282,38 @@ int step_with_exchange(lbm_ctx* c, int src, int dst, int t) {
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
     c->comm_issued = true;
-    if (hi > lo) {
-        a.y_lo = lo; a.y_cnt = hi - lo;
-        a.reverse = (c->alternate && (t & 1)) ? 1 : 0;
-        launch_rows<T, MODE_STEP>(c, a, c->stream);
+    if (c->nyl - e0 - e1 > 0) {
+        launch(e0, c->nyl - e0 - e1, rev);
         HIPCHK(hipGetLastError());
     }
     return LBM_OK;
+}
+
+// One launch without neighbours.
+template <typename T>
+int advance_local(lbm_ctx* c, int src, int dst, int t, bool pair) {
+    return launch_step<T>(c, src, dst, t, pair ? 100 : MODE_STEP, c->stream);
+}
+
+// Advance by up to `remaining` iterations with ONE launch; returns the number of iterations taken (1 or 2) or <0.
+// Two are fused only when the plan allows it, when iteration t+1 is not a force-output iteration (its post-collision
+// state would never exist in memory) and when at least one more iteration follows inside this call, so that the last
+// launch of every lbm_step call is a single iteration and buf[cur^1] holds the previous iteration's populations
+// (macro snapshot / f_current accessors).
+template <typename T>
+int advance(lbm_ctx* c, int remaining, int of, bool exchange) {
+    const int t = c->steps_done;
+    const bool pair = c->pair && pair_possible(c) && remaining >= (c->trailing_pair ? 2 : 3) &&
+                      !(of > 0 && (t + 1) % of == 0) &&
+                      (!exchange || c->nyl >= 2 * GR);
+    const int src = c->cur, dst = c->cur ^ 1;
+    int rc = exchange ? advance_with_exchange<T>(c, src, dst, t, pair) : advance_local<T>(c, src, dst, t, pair);
+    if (rc) return rc;
+    c->cur = dst;
+    c->steps_done = t + (pair ? 2 : 1);
+    c->launches_total++;
+    c->last_was_pair = pair;
+    return pair ? 2 : 1;
 }
 
 // Make everything issued so far (both streams) visible to work queued on the compute stream afterwards.
@@ -285,7 +333,7 @@ int init_state(lbm_ctx* c) {
     for (int i = 0; i < Q; ++i) ia.feq_in[i] = (T)c->feq_in[i];
     ia.solid_count = c->d_solid_count;
     HIPCHK(hipMemsetAsync(c->d_solid_count, 0, sizeof(int), c->stream));
-    dim3 grid((c->nx + 2 + 255) / 256, c->nyl + 2), block(256);
+    dim3 grid((c->nx + 2 + 255) / 256, c->nyl + 2 * GR), block(256);
     hipLaunchKernelGGL((k_init<T>), grid, block, 0, c->stream, ia);
     HIPCHK(hipGetLastError());
     // collision_step of iteration 0: initial state (buf 0) -> P_0 (buf 1)
@@ -314,64 +362,75 @@ inline int alloc_buffers(lbm_ctx* c) {
 // 4096x1024 fp64 depending on the allocation). All candidates compute bit-identical results, so lbm_initialise
 // times each one on the real buffers (8 warm-up + 24 timed launches, a few ms) and keeps the fastest together
 // with the very allocation it was measured on.
-struct Plan { int layout, variant, nt, alternate; const char* name; };
+struct Plan { int layout, variant, nt, alternate, pair, ty; const char* name; };
+
+inline void apply_plan(lbm_ctx* c, const Plan& pl) {
+    configure_layout(c, pl.layout);
+    c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate; c->pair = pl.pair;
+    if (pl.ty) c->pair_ty = pl.ty;
+}
 
 template <typename T>
 int time_plan(lbm_ctx* c, float* ms_out) {
     int rc = init_state<T>(c);
     if (rc) return rc;
     auto run = [&](int n) -> int {
-        for (int k = 0; k < n; ++k) {
-            const int t = c->steps_done, dst = c->cur ^ 1;
-            int r = launch_step<T>(c, c->cur, dst, t, MODE_STEP, c->stream);
-            if (r) return r;
-            c->cur = dst;
-            c->steps_done = t + 1;
+        for (int k = 0; k < n;) {
+            const int took = advance<T>(c, n - k + 2, 0, false);   // +2: never end on the "last is single" rule
+            if (took < 0) return took;
+            k += took;
         }
         return LBM_OK;
     };
     rc = run(8);
     if (rc) return rc;
+    const int t0 = c->steps_done;
     HIPCHK(hipEventRecord(c->ev_t0, c->stream));
     rc = run(24);
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->ev_t1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev_t1));
     HIPCHK(hipEventElapsedTime(ms_out, c->ev_t0, c->ev_t1));
-    *ms_out /= 24.f;
+    *ms_out /= (float)(c->steps_done - t0);     // per iteration
     return LBM_OK;
 }
 
 template <typename T>
 int choose_plan(lbm_ctx* c) {
-    const Plan fixed = {c->layout, c->variant, c->use_nt, c->alternate, "fixed by options"};
+    const bool strips = c->comm && c->nranks > 1;
+    const Plan fixed = {strips ? 1 : c->layout, c->variant, c->use_nt, c->alternate, c->pair, c->pair_ty, "fixed by options"};
     std::vector<Plan> cand;
-    const bool vec_ok = (c->nx % vec_width<T>() == 0);
+    const bool vec_ok = (c->nx % vec_width<T>() == 0), p2 = pair_possible(c);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     configure_layout(c, 1);
     const size_t need = 2 * buffer_bytes(c);
     // tiny grids are launch/latency bound (nothing to choose); huge ones cannot afford a second live allocation
-    const bool can_tune = c->tune && (size_t)c->nx * c->nyl >= (1u << 20) && 2 * need + (1u << 28) < free_b;
+    const bool can_tune = c->tune && (size_t)c->nx * c->nyl >= (1u << 19) && 2 * need + (1u << 28) < free_b;
     if (!c->tune) cand.push_back(fixed);
-    else if (!can_tune) cand.push_back({0, vec_ok ? 0 : 1, 0, 1, "planar/alternate (default, not measured)"});
-    else {
-        if (vec_ok) cand.push_back({0, 0, 0, 1, "planar/vec16B/alternate"});
-        cand.push_back({1, 1, 1, 0, "row-interleaved/site/nt-store"});
-        cand.push_back({1, 1, 0, 1, "row-interleaved/site/alternate"});
-        if (vec_ok) cand.push_back({1, 0, 1, 0, "row-interleaved/vec16B/nt-store"});
-        if (vec_ok) cand.push_back({1, 0, 0, 0, "row-interleaved/vec16B"});
-        cand.push_back({0, 1, 0, 1, "planar/site/alternate"});
-        if (vec_ok) cand.push_back({0, 0, 0, 1, "planar/vec16B/alternate (2nd allocation)"});
+    else if (!can_tune) {
+        if (strips) cand.push_back({1, 1, 0, 1, p2 ? 1 : 0, 8, "row-interleaved (default, not measured)"});
+        else cand.push_back({0, vec_ok ? 0 : 1, 0, 1, p2 ? 1 : 0, 8, "planar (default, not measured)"});
+    } else {
+        // strips exchange GR rows x 9 sub-rows as one contiguous run: row-interleaved only
+        if (p2) cand.push_back({1, 1, 1, 0, 1, 8, "row-interleaved/2-step 64x8/nt-store"});
+        if (p2) cand.push_back({1, 1, 1, 0, 1, 12, "row-interleaved/2-step 64x12/nt-store"});
+        if (p2) cand.push_back({1, 1, 0, 1, 1, 8, "row-interleaved/2-step 64x8/alternate"});
+        cand.push_back({1, 1, 1, 0, 0, 0, "row-interleaved/site/nt-store"});
+        cand.push_back({1, 1, 0, 1, 0, 0, "row-interleaved/site/alternate"});
+        if (!strips) {
+            if (p2) cand.push_back({0, 0, 1, 0, 1, 8, "planar/2-step 64x8/nt-store"});
+            if (p2) cand.push_back({0, 0, 1, 0, 1, 12, "planar/2-step 64x12/nt-store"});
+            if (p2) cand.push_back({0, 0, 0, 1, 1, 8, "planar/2-step 64x8/alternate"});
+            if (vec_ok) cand.push_back({0, 0, 0, 1, 0, 0, "planar/vec16B/alternate"});
+            cand.push_back({0, 1, 0, 1, 0, 0, "planar/site/alternate"});
+        }
     }
     void* best_buf[2] = {nullptr, nullptr};
     float best_ms = 1e30f;
     int best = -1;
-    std::string log;
     for (size_t k = 0; k < cand.size(); ++k) {
-        const Plan& pl = cand[k];
-        configure_layout(c, pl.layout);
-        c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate;
+        apply_plan(c, cand[k]);
         c->buf[0] = c->buf[1] = nullptr;            // keep the best allocation alive while the next one is probed
         int rc = alloc_buffers(c);
         if (rc) { c->buf[0] = best_buf[0]; c->buf[1] = best_buf[1]; return rc; }
@@ -388,13 +447,13 @@ int choose_plan(lbm_ctx* c) {
             free_buffers(c);
         }
     }
-    const Plan& pl = cand[best];
-    configure_layout(c, pl.layout);
-    c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate;
+    apply_plan(c, cand[best]);
     c->buf[0] = best_buf[0]; c->buf[1] = best_buf[1];
-    if (cand.size() > 1) snprintf(c->plan_desc, sizeof(c->plan_desc), "%s (fastest of %zu measured, %.1f us/step)", pl.name,
-                                  cand.size(), best_ms * 1e3f);
-    else snprintf(c->plan_desc, sizeof(c->plan_desc), "%s", pl.name);
+    c->launches_total = 0;
+    c->last_was_pair = false;
+    if (cand.size() > 1) snprintf(c->plan_desc, sizeof(c->plan_desc), "%s (fastest of %zu measured, %.1f us/iteration)",
+                                  cand[best].name, cand.size(), best_ms * 1e3f);
+    else snprintf(c->plan_desc, sizeof(c->plan_desc), "%s", cand[best].name);
     return LBM_OK;
 }
 
@@ -416,7 +475,9 @@ int do_initialise(lbm_ctx* c) {
 template <typename T>
 int do_steps(lbm_ctx* c, int nsteps, int of) {
     if (c->timing) HIPCHK(hipEventRecord(c->ev_t0, c->stream));
-    for (int k = 0; k < nsteps; ++k) {
+    const bool exchange = c->comm && c->nranks > 1;
+    int launches = 0;
+    for (int k = 0; k < nsteps;) {
         const int t = c->steps_done;
         if (of > 0 && t % of == 0) {
             if (c->log_count >= c->log_cap) return fail(LBM_ERR_ARG, "force log full (%d rows): drain it", c->log_cap);
@@ -424,16 +485,15 @@ int do_steps(lbm_ctx* c, int nsteps, int of) {
             if (rc) return rc;
             c->log_count++;
         }
-        const int src = c->cur, dst = c->cur ^ 1;
-        int rc = (c->comm && c->nranks > 1) ? step_with_exchange<T>(c, src, dst, t)
-                                            : launch_step<T>(c, src, dst, t, MODE_STEP, c->stream);
-        if (rc) return rc;
-        c->cur = dst;
-        c->steps_done = t + 1;
+        const int took = advance<T>(c, nsteps - k, of, exchange);
+        if (took < 0) return took;
+        k += took;
+        ++launches;
     }
     if (c->timing) {
         HIPCHK(hipEventRecord(c->ev_t1, c->stream));
-        c->timed_launches = nsteps;
+        c->timed_launches = launches;
+        c->timed_steps = nsteps;
     }
     return LBM_OK;
 }
@@ -483,7 +543,7 @@ int do_populations(lbm_ctx* c, int which, double* aos) {
             const bool analytic = ghost && (which == 0 || initial);
             for (int i = 0; i < Q; ++i)
                 o[i] = analytic ? (double)(T)c->feq_in[i]
-                                : (double)host[(size_t)i * c->plane + (size_t)gy * c->pitch + c->xoff + gx - 1];
+                                : (double)host[(size_t)i * c->plane + (size_t)(gy + GR - 1) * c->pitch + c->xoff + gx - 1];
         }
     return LBM_OK;
 }
@@ -491,17 +551,17 @@ int do_populations(lbm_ctx* c, int which, double* aos) {
 template <typename T>
 int do_halo_export(lbm_ctx* c, double* south_out, double* north_out) {
     const T* base = static_cast<const T*>(c->buf[c->cur]);
-    const size_t n3 = 3 * (size_t)c->nx;
-    dim3 grid((c->nx + 255) / 256), block(256);
-    if (south_out) {
-        hipLaunchKernelGGL((k_halo_pack<T>), grid, block, 0, c->stream, base, (long)c->plane,
-                           (long)1 * c->pitch + c->xoff, c->nx, 4, 7, 8, c->d_halo);
-        HIPCHK(hipMemcpyAsync(south_out, c->d_halo, n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    const size_t n = (size_t)GR * Q * c->nx;
+    dim3 grid((c->nx + 255) / 256, GR * Q), block(256);
+    if (south_out) {   // my bottom GR interior rows
+        hipLaunchKernelGGL((k_halo_pack<T>), grid, block, 0, c->stream, base, (long)c->plane, c->pitch, c->xoff, c->nx, GR,
+                           c->d_halo);
+        HIPCHK(hipMemcpyAsync(south_out, c->d_halo, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    if (north_out) {
-        hipLaunchKernelGGL((k_halo_pack<T>), grid, block, 0, c->stream, base, (long)c->plane,
-                           (long)c->nyl * c->pitch + c->xoff, c->nx, 2, 5, 6, c->d_halo + n3);
-        HIPCHK(hipMemcpyAsync(north_out, c->d_halo + n3, n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (north_out) {   // my top GR interior rows
+        hipLaunchKernelGGL((k_halo_pack<T>), grid, block, 0, c->stream, base, (long)c->plane, c->pitch, c->xoff, c->nx,
+                           c->nyl, c->d_halo + n);
+        HIPCHK(hipMemcpyAsync(north_out, c->d_halo + n, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     return LBM_OK;
@@ -510,17 +570,17 @@ int do_halo_export(lbm_ctx* c, double* south_out, double* north_out) {
 template <typename T>
 int do_halo_import(lbm_ctx* c, const double* south_in, const double* north_in) {
     T* base = static_cast<T*>(c->buf[c->cur]);
-    const size_t n3 = 3 * (size_t)c->nx;
-    dim3 grid((c->nx + 255) / 256), block(256);
-    if (south_in) {
-        HIPCHK(hipMemcpyAsync(c->d_halo + 2 * n3, south_in, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL((k_halo_unpack<T>), grid, block, 0, c->stream, base, (long)c->plane, (long)c->xoff, c->nx,
-                           2, 5, 6, c->d_halo + 2 * n3);
+    const size_t n = (size_t)GR * Q * c->nx;
+    dim3 grid((c->nx + 255) / 256, GR * Q), block(256);
+    if (south_in) {    // -> south ghost rows gy = 0 .. GR-1
+        HIPCHK(hipMemcpyAsync(c->d_halo + 2 * n, south_in, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL((k_halo_unpack<T>), grid, block, 0, c->stream, base, (long)c->plane, c->pitch, c->xoff, c->nx, 0,
+                           c->d_halo + 2 * n);
     }
-    if (north_in) {
-        HIPCHK(hipMemcpyAsync(c->d_halo + 3 * n3, north_in, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL((k_halo_unpack<T>), grid, block, 0, c->stream, base, (long)c->plane,
-                           (long)(c->nyl + 1) * c->pitch + c->xoff, c->nx, 4, 7, 8, c->d_halo + 3 * n3);
+    if (north_in) {    // -> north ghost rows gy = nyl+GR .. nyl+2GR-1
+        HIPCHK(hipMemcpyAsync(c->d_halo + 3 * n, north_in, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL((k_halo_unpack<T>), grid, block, 0, c->stream, base, (long)c->plane, c->pitch, c->xoff, c->nx,
+                           c->nyl + GR, c->d_halo + 3 * n);
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     return LBM_OK;
@@ -599,7 +659,7 @@ int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
     HIPTRY(hipMalloc(&c->d_maxbits, sizeof(unsigned long long)));
     HIPTRY(hipMalloc(&c->d_force_now, 3 * sizeof(double)));
     HIPTRY(hipMalloc(&c->d_force_log, 3 * sizeof(double) * c->log_cap));
-    HIPTRY(hipMalloc(&c->d_halo, 4 * 3 * sizeof(double) * (size_t)c->nx));
+    HIPTRY(hipMalloc(&c->d_halo, 4 * GR * Q * sizeof(double) * (size_t)c->nx));
     HIPTRY(hipMalloc(&c->d_red, 64 * sizeof(double)));
 #undef HIPTRY
     *out = c;
@@ -701,6 +761,7 @@ int lbm_drain_force_log(lbm_ctx* c, lbm_force_row* rows, int max_rows) {
 
 int lbm_get_macros(lbm_ctx* c, double* rho, double* ux, double* uy) {
     if (!c || !c->initialised) return fail(LBM_ERR_ARG, "context not initialised");
+    if (c->last_was_pair) return fail(LBM_ERR_ARG, "snapshot unavailable: the last launch fused two iterations (trailing_pair); take one more lbm_step(c,1,..)");
     HIPCHK(hipSetDevice(c->device));
     { int jr = join_comm(c); if (jr) return jr; }
     int rc = DISPATCH(c, do_macros<double>(c, false), do_macros<float>(c, false));
@@ -715,6 +776,7 @@ int lbm_get_macros(lbm_ctx* c, double* rho, double* ux, double* uy) {
 
 int lbm_max_velocity_sq(lbm_ctx* c, double* out) {
     if (!c || !c->initialised || !out) return fail(LBM_ERR_ARG, "bad argument");
+    if (c->last_was_pair) return fail(LBM_ERR_ARG, "snapshot unavailable: the last launch fused two iterations (trailing_pair); take one more lbm_step(c,1,..)");
     HIPCHK(hipSetDevice(c->device));
     { int jr = join_comm(c); if (jr) return jr; }
     int rc = DISPATCH(c, do_macros<double>(c, true), do_macros<float>(c, true));
@@ -728,6 +790,7 @@ int lbm_max_velocity_sq(lbm_ctx* c, double* out) {
 
 int lbm_get_populations(lbm_ctx* c, int which, double* aos) {
     if (!c || !c->initialised || !aos || (which != 0 && which != 1)) return fail(LBM_ERR_ARG, "bad argument");
+    if (c->last_was_pair) return fail(LBM_ERR_ARG, "snapshot unavailable: the last launch fused two iterations (trailing_pair); take one more lbm_step(c,1,..)");
     HIPCHK(hipSetDevice(c->device));
     { int jr = join_comm(c); if (jr) return jr; }
     return DISPATCH(c, do_populations<double>(c, which, aos), do_populations<float>(c, which, aos));
@@ -762,6 +825,7 @@ int lbm_comm_init(lbm_ctx* c, int rank, int nranks, const void* id128) {
     NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
     c->rank = rank;
     c->nranks = nranks;
+    if (nranks > 1 && c->nyl < GR) return fail(LBM_ERR_ARG, "a strip with neighbours needs at least %d rows", GR);
     return LBM_OK;
 }
 
@@ -794,13 +858,16 @@ int lbm_halo_import(lbm_ctx* c, const double* south_in, const double* north_in) 
 int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     if (!c || !key) return fail(LBM_ERR_ARG, "null argument");
     const std::string k(key);
-    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune"))
+    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune" || k == "pair" || k == "pair_ty"))
         return fail(LBM_ERR_ARG, "option %s must be set before lbm_initialise", key);
     if (k == "variant") c->variant = (int)value;
     else if (k == "timing") c->timing = (int)value;
     else if (k == "alternate") c->alternate = (int)value;
     else if (k == "layout") c->layout = (int)value ? 1 : 0;
     else if (k == "nt") c->use_nt = (int)value ? 1 : 0;
+    else if (k == "pair") c->pair = (int)value ? 1 : 0;
+    else if (k == "trailing_pair") c->trailing_pair = (int)value ? 1 : 0;
+    else if (k == "pair_ty") { if (value != 8 && value != 12) return fail(LBM_ERR_ARG, "pair_ty must be 8 or 12"); c->pair_ty = (int)value; }
     else if (k == "tune") c->tune = (int)value ? 1 : 0;
     else if (k == "overlap") c->overlap = (int)value;
     else return fail(LBM_ERR_ARG, "unknown option %s", key);
@@ -819,13 +886,29 @@ int lbm_last_step_kernel_ms(lbm_ctx* c, double* ms_per_launch) {
     return LBM_OK;
 }
 
+int lbm_last_step_stats(lbm_ctx* c, double* ms_total, int* launches, int* iterations) {
+    if (!c) return fail(LBM_ERR_ARG, "null argument");
+    if (ms_total) *ms_total = 0.0;
+    if (launches) *launches = c->timed_launches;
+    if (iterations) *iterations = c->timed_steps;
+    if (!c->timing || c->timed_launches <= 0) return LBM_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->ev_t1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+    if (ms_total) *ms_total = (double)ms;
+    return LBM_OK;
+}
+
 const char* lbm_kernel_name(const lbm_ctx* c) {
     if (!c) return "";
-    const bool f32 = c->p.precision == LBM_PRECISION_F32;
-    if (use_vec(c)) return f32 ? (c->use_nt ? "k_step_vec<float,4,0,true>" : "k_step_vec<float,4,0,false>")
-                               : (c->use_nt ? "k_step_vec<double,2,0,true>" : "k_step_vec<double,2,0,false>");
-    return f32 ? (c->use_nt ? "k_step_site<float,0,true>" : "k_step_site<float,0,false>")
-               : (c->use_nt ? "k_step_site<double,0,true>" : "k_step_site<double,0,false>");
+    static thread_local char name[96];
+    const char* t = c->p.precision == LBM_PRECISION_F32 ? "float" : "double";
+    const char* nt = c->use_nt ? "true" : "false";
+    if (c->pair && pair_possible(c)) snprintf(name, sizeof(name), "k_step2_tile<%s,%d,%d,%s>", t, c->pair_ty, c->pair_ty == 12 ? 768 : 512, nt);
+    else if (use_vec(c)) snprintf(name, sizeof(name), "k_step_vec<%s,%d,0,%s>", t, (int)(16 / c->esize), nt);
+    else snprintf(name, sizeof(name), "k_step_site<%s,0,%s>", t, nt);
+    return name;
 }
 
 const char* lbm_plan(const lbm_ctx* c) { return c ? c->plan_desc : ""; }

@@ -3,8 +3,10 @@
 // One persistent state per strip: the POST-COLLISION populations P_t (the reference's f_next right after
 // collision_step() of iteration t, LBMSolver.h:84-126), stored as 9 SoA planes with a one-cell ghost frame:
 //
-//     plane i, local row gy in [0, ny_loc+2), column col:   base[i*plane + gy*pitch + col]
-//     interior cell (x, y)  <->  gy = y+1, col = xoff + x       (xoff*sizeof(T) is a multiple of 128 B)
+//     plane i, local row gy in [0, ny_loc+2*GR), column col:   base[i*plane + gy*pitch + col]
+//     interior cell (x, y)  <->  gy = y+GR, col = xoff + x      (xoff*sizeof(T) is a multiple of 128 B)
+// GR = 2 ghost rows on each side (the two-step kernel of a strip needs its neighbours' two edge rows); one ghost
+// column on each side.
 // The two strides describe either of two layouts chosen by the host (lbm_hip.hip, "plan"):
 //     PLANAR          plane = rows*pitch0 (+pad), pitch = pitch0            nine separate planes
 //     ROW-INTERLEAVED plane = pitch0,             pitch = 9*pitch0          [gy][i][col]: the nine sub-rows of a
@@ -30,6 +32,7 @@
 namespace lbmk {
 
 constexpr int Q = 9;
+constexpr int GR = 2;   // ghost rows below and above the strip
 // LBMConfig.h:13-34 — direction numbering is observable through f_current(x,y,i), keep it.
 __host__ __device__ constexpr int cx(int i) { constexpr int v[Q] = {0, 1, 0, -1, 0, 1, -1, -1, 1}; return v[i]; }
 __host__ __device__ constexpr int cy(int i) { constexpr int v[Q] = {0, 0, 1, 0, -1, 1, 1, -1, -1}; return v[i]; }
@@ -138,7 +141,7 @@ __global__ void __launch_bounds__(256) k_step_site(const KArgs<T> a) {
     const int y = row_of_block(a);
     if (x >= a.nx) return;
     const int yg = a.y_start + y;
-    const long c = (long)(y + 1) * a.pitch + a.xoff + x;
+    const long c = (long)(y + GR) * a.pitch + a.xoff + x;
     T f[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
@@ -188,7 +191,7 @@ __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
     const int y = row_of_block(a);
     if (x0 >= a.nx) return;
     const int yg = a.y_start + y;
-    const long c = (long)(y + 1) * a.pitch + a.xoff + x0;
+    const long c = (long)(y + GR) * a.pitch + a.xoff + x0;
     VA fv[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
@@ -243,6 +246,81 @@ __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
     }
 }
 
+// Two timesteps per launch: temporal blocking through LDS. A block owns a TX x TY tile of outputs at iteration
+// t+1. Phase 1 computes P_{t+1} on the (TX+2) x (TY+2) region around it from global P_t — the step kernel's
+// per-cell sequence, with cells outside the domain taking their permanent ghost constants (N1/N2) and solid cells
+// w_i — into LDS; after one barrier phase 2 pulls from LDS, applies the BCs of iteration t+1, collides and stores
+// P_{t+2}. P_{t+1} never touches HBM: traffic per lattice update drops from 144 B to ~(1 + (TX+2)(TY+2)/(TX TY))*36 B
+// (82 B at 64x8, less when the tile halo is still in L2 / Infinity Cache). Same arithmetic per cell => results
+// bit-identical to two k_step_site launches (tests). Requires nx % 64 == 0; rows of neighbouring strips must be
+// present two deep (GR = 2). LDS: 9*(TY+2)*(TX+4)*sizeof(T) (47.9 KB at TY=8, fp64: three blocks per CU).
+template <typename T> struct K2Extra { T feq_in[Q]; };
+
+template <typename T, int TY, int NTH, bool NT>
+__global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Extra<T> e) {
+    constexpr int TX = 64, RW = TX + 2, RH = TY + 2, LP = RW + 2;
+    __shared__ T lds[Q][RH][LP];
+    const int X0 = blockIdx.x * TX;
+    const int by = a.reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+    const int Y0 = a.y_lo + by * TY;
+    const int y_end = a.y_lo + a.y_cnt;                        // rows >= y_end belong to another launch
+    bool bad = false;
+    for (int r = threadIdx.x; r < RW * RH; r += NTH) {         // phase 1: iteration t on the region
+        const int ry = r / RW, rx = r - ry * RW;
+        const int x = X0 + rx - 1, y = Y0 + ry - 1;
+        if (y > y_end) continue;                               // partial last tile: not needed by any output
+        const int yg = a.y_start + y;
+        const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+        T f[Q];
+        if (!(row_in && col_in)) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = (row_in && !col_in) ? T(0) : e.feq_in[i];
+        } else {
+            const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
+            const bool solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+            T rho_bc, u_out;
+            if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+            bad |= any_unstable(f);
+            if (solid) {
+#pragma unroll
+                for (int i = 0; i < Q; ++i) f[i] = wgt<T>(i);
+            } else {
+                bgk_collide(f, a.tau_inv);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
+    }
+    if (bad) atomicMin(a.unstable_t, a.t);
+    __syncthreads();
+    bad = false;
+    for (int o = threadIdx.x; o < TX * TY; o += NTH) {         // phase 2: iteration t+1 on the tile
+        const int ly = o / TX, lx = o - ly * TX;
+        const int x = X0 + lx, y = Y0 + ly;
+        if (y >= y_end) continue;
+        const int yg = a.y_start + y;
+        T f[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) f[i] = lds[i][ly + 1 - cy(i)][lx + 1 - cx(i)];
+        const bool solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+        T rho_bc, u_out;
+        if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+        bad |= any_unstable(f);
+        if (solid) continue;
+        bgk_collide(f, a.tau_inv);
+        const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            T* p = a.dst + (long)i * a.plane + c;
+            if (NT) __builtin_nontemporal_store(f[i], p);
+            else *p = f[i];
+        }
+    }
+    if (bad) atomicMin(a.unstable_t, a.t + 1);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Initialisation: Grid::initialise (LBMGrid.h:185-246) written into BOTH buffers, plus the permanent ghost
 // values of N1/N2 (see top of file). feq_in = f_eq(1,(u_in,0)) evaluated on the host in double with the
@@ -259,12 +337,12 @@ struct InitArgs {
 template <typename T>
 __global__ void __launch_bounds__(256) k_init(const InitArgs<T> p) {
     const int gx = blockIdx.x * 256 + threadIdx.x;   // 0 .. nx+1  (ghost-inclusive column)
-    const int gy = blockIdx.y;                       // 0 .. ny_loc+1
+    const int gy = blockIdx.y;                       // 0 .. ny_loc+2*GR-1
     if (gx > p.nx + 1) return;
-    const int x = gx - 1, yg = p.y_start + gy - 1;   // global coordinates (may be -1 / nx / ny)
+    const int x = gx - 1, yg = p.y_start + gy - GR;  // global coordinates (may lie outside the domain)
     const bool row_interior = (yg >= 0 && yg < p.ny_glob);
     const bool col_interior = (x >= 0 && x < p.nx);
-    const bool own_row = (gy >= 1 && gy <= p.ny_loc);
+    const bool own_row = (gy >= GR && gy < p.ny_loc + GR);
     bool solid = false;
     if (row_interior && col_interior) solid = is_solid_cell(x, yg, p.cyl_x, p.cyl_y, p.cyl_r2);
     if (solid && own_row) atomicAdd(p.solid_count, 1);
@@ -302,7 +380,7 @@ __global__ void __launch_bounds__(256) k_macros(const MacroArgs<T> p) {
     double usq = 0.0;
     if (x < p.nx) {
         const int yg = p.y_start + y;
-        const long c = (long)(y + 1) * p.pitch + p.xoff + x;
+        const long c = (long)(y + GR) * p.pitch + p.xoff + x;
         const bool solid = is_solid_cell(x, yg, p.cyl_x, p.cyl_y, p.cyl_r2);
         double r, vx, vy;
         if (solid) { r = 1.0; vx = 0.0; vy = 0.0; }
@@ -364,7 +442,7 @@ __global__ void __launch_bounds__(1024) k_forces(const ForceArgs<T> p) {
         const int x = p.x0 + (int)(k % bw), y = p.y0 + (int)(k / bw);
         const int yg = p.y_start + y;
         if (is_solid_cell(x, yg, p.cyl_x, p.cyl_y, p.cyl_r2)) continue;
-        const long c = (long)(y + 1) * p.pitch + p.xoff + x;
+        const long c = (long)(y + GR) * p.pitch + p.xoff + x;
 #pragma unroll
         for (int i = 1; i < Q; ++i) {
             const int sx = x + cx(i), sy = yg + cy(i);
@@ -385,22 +463,25 @@ __global__ void __launch_bounds__(1024) k_forces(const ForceArgs<T> p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Host-staged halo rows (lbm_halo_export / lbm_halo_import): 3 planes x nx elements per face, as double.
+// Host-staged halo rows (lbm_halo_export / lbm_halo_import): GR rows x 9 planes x nx interior columns per face,
+// as double, [GR][9][nx]. `row0` = first local gy of the GR consecutive rows.
 template <typename T>
-__global__ void __launch_bounds__(256) k_halo_pack(const T* buf, long plane, long row_off, int nx, int i0, int i1,
-                                                   int i2, double* out) {
+__global__ void __launch_bounds__(256) k_halo_pack(const T* buf, long plane, int pitch, int xoff, int nx, int row0,
+                                                   double* out) {
     const int x = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;          // 0 .. GR*Q-1  = row-major (row, plane)
     if (x >= nx) return;
-    const int ids[3] = {i0, i1, i2};
-    for (int k = 0; k < 3; ++k) out[(long)k * nx + x] = (double)buf[(long)ids[k] * plane + row_off + x];
+    const int r = k / Q, i = k - r * Q;
+    out[(long)k * nx + x] = (double)buf[(long)i * plane + (long)(row0 + r) * pitch + xoff + x];
 }
 template <typename T>
-__global__ void __launch_bounds__(256) k_halo_unpack(T* buf, long plane, long row_off, int nx, int i0, int i1, int i2,
+__global__ void __launch_bounds__(256) k_halo_unpack(T* buf, long plane, int pitch, int xoff, int nx, int row0,
                                                      const double* in) {
     const int x = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
     if (x >= nx) return;
-    const int ids[3] = {i0, i1, i2};
-    for (int k = 0; k < 3; ++k) buf[(long)ids[k] * plane + row_off + x] = (T)in[(long)k * nx + x];
+    const int r = k / Q, i = k - r * Q;
+    buf[(long)i * plane + (long)(row0 + r) * pitch + xoff + x] = (T)in[(long)k * nx + x];
 }
 
 }  // namespace lbmk

@@ -20,12 +20,12 @@ def main():
     lbm = importlib.import_module(PKG)
     y0, nloc = lbm.partition_rows(ny, world)[rank]
     kw = dict(tau=0.6, inlet_velocity=0.06, cylinder_radius=0.12)
-    halo = lbm.GlooHalo(rank, world, nx)
     forces = []
 
     if backend == "oracle":
         from oracle.oracle import Oracle, make_params
         o = Oracle(make_params(nx, ny, **kw), y0, nloc)
+        halo = lbm.GlooHalo(rank, world, (3, nx))     # the oracle's one-iteration pull consumes 3 populations per face
 
         def export_fn(s, n):
             so = o.edge_row(False).reshape(nx, 9)[:, lbm.strips.DOWN].T.copy() if s else None
@@ -48,7 +48,11 @@ def main():
             assert o.stable()
         macros = (o.rho.copy(), o.ux.copy(), o.uy.copy())
     else:
-        ctx = lbm.Context(nx, ny, y_start=y0, local_ny=nloc, device=0, **kw)
+        pairs = backend.endswith("-pair")
+        backend = backend.replace("-pair", "")
+        opts = dict(tune=0, layout=1, variant=1, nt=1, pair=1, trailing_pair=1) if pairs else None
+        ctx = lbm.Context(nx, ny, y_start=y0, local_ny=nloc, device=0, options=opts, **kw)
+        halo = lbm.GlooHalo(rank, world, (ctx.HALO_ROWS, 9, nx))
         if backend == "hip-rccl":
             ident = [ctx.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ident, src=0)
@@ -63,8 +67,12 @@ def main():
         else:
             ctx.initialise()
             halo.exchange(ctx.halo_export, ctx.halo_import)
-            for _ in range(steps):
-                ctx.step(1, of)
+            done = 0
+            while done < steps:
+                # with pairs: two iterations per launch (one exchange per launch), the last one single
+                n = 2 if (pairs and steps - done >= 3 and (done + 1) % of != 0) else 1
+                ctx.step(n, of)
+                done += n
                 halo.exchange(ctx.halo_export, ctx.halo_import)
         assert ctx.first_unstable_step() == -1
         forces = ctx.drain_force_log()

@@ -33,6 +33,9 @@ PLANS = {
     "planar-site": dict(tune=0, layout=0, variant=1, nt=0, alternate=0),
     "rowil-site-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0),
     "rowil-vec-nt-alt": dict(tune=0, layout=1, variant=0, nt=1, alternate=1),
+    # two iterations fused per launch through LDS (k_step2_tile; falls back to one per launch when nx % 64 != 0)
+    "planar-pair8-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, pair=1, pair_ty=8),
+    "rowil-pair12-alt": dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair=1, pair_ty=12),
 }
 
 
@@ -127,8 +130,10 @@ def test_golden_unstable_timestep(lbm, name, plan):
     (300, 3, 50, dict(cylinder_x=-1.0, cylinder_radius=0.0)),        # one interior row between the walls
     (1024, 256, 500, dict(inlet_velocity=0.13020833)),
     (2048, 512, 120, dict(inlet_velocity=0.1)),                      # large enough for the measured plan
+    (128, 70, 333, dict(inlet_velocity=0.09, cylinder_radius=0.1)),  # nx % 64 == 0, ny not a multiple of the tile
+    (64, 9, 45, dict(cylinder_x=-1.0, cylinder_radius=0.0)),          # a single tile column, partial second tile row
 ])
-@pytest.mark.parametrize("plan", ["auto", "planar-site", "rowil-vec-nt-alt"])
+@pytest.mark.parametrize("plan", ["auto", "planar-site", "rowil-vec-nt-alt", "planar-pair8-nt", "rowil-pair12-alt"])
 def test_against_oracle(lbm, nx, ny, steps, kw, plan):
     from oracle.oracle import Oracle, make_params
     of = max(1, steps // 5)
@@ -168,10 +173,17 @@ def test_initial_state_accessors(lbm):
         assert np.array_equal(ctx.populations("f_next"), o.f_next)
 
 
-def _run_strips(lbm, nx, ny, bounds, steps, of, precision="f64", plans=None, **kw):
-    """Strips on one GPU, host-staged halo exchange (lbm_halo_export/import), one step at a time."""
+def _run_strips(lbm, nx, ny, bounds, steps, of, precision="f64", plans=None, pairs=False, **kw):
+    """Strips on one GPU, host-staged halo exchange (lbm_halo_export/import) after every launch. pairs: launches
+    fuse two iterations (trailing_pair) wherever the force cadence allows; the last launch is a single iteration."""
     plans = plans or [None] * len(bounds)
-    ctxs = [lbm.Context(nx, ny, y_start=y0, local_ny=n, precision=precision, options=PLANS[pl] if pl else None, **kw)
+
+    def opts(pl):
+        o = dict(PLANS[pl]) if pl else {}
+        if pairs:
+            o.update(trailing_pair=1)
+        return o or None
+    ctxs = [lbm.Context(nx, ny, y_start=y0, local_ny=n, precision=precision, options=opts(pl), **kw)
             for (y0, n), pl in zip(bounds, plans)]
     solid = sum(c.initialise() for c in ctxs)
 
@@ -181,9 +193,12 @@ def _run_strips(lbm, nx, ny, bounds, steps, of, precision="f64", plans=None, **k
             c.halo_import(south=ex[k - 1][1] if k > 0 else None,
                           north=ex[k + 1][0] if k < len(ctxs) - 1 else None)
     exchange()                            # P_0 edge rows
-    for _ in range(steps):
+    done = 0
+    while done < steps:
+        n = 2 if (pairs and steps - done >= 3 and (of <= 0 or (done + 1) % of != 0)) else 1
         for c in ctxs:
-            c.step(1, of)
+            c.step(n, of)
+        done += n
         exchange()
     return ctxs, solid
 
@@ -216,13 +231,48 @@ def test_strips_match_single_domain_bitwise(lbm):
         c.close()
 
 
+def test_strips_with_fused_pairs_match_single_domain_bitwise(lbm):
+    """Strips whose launches fuse two iterations: the two-deep halo (LBM_HALO_ROWS) makes the recomputed edge rows
+    identical to the neighbour's own; result == the one-domain run, bit for bit."""
+    nx, ny, steps, of = 192, 60, 121, 40
+    kw = dict(inlet_velocity=0.06, cylinder_radius=0.12)
+    with lbm.Context(nx, ny, options=PLANS["planar-site"], **kw) as whole:
+        whole.initialise()
+        whole.step(steps, of)
+        w = whole.macros()
+        w_fn = whole.populations("f_next")
+        w_log = whole.drain_force_log()
+    ctxs, _ = _run_strips(lbm, nx, ny, [(0, 25), (25, 8), (33, 27)], steps, of, pairs=True,
+                          plans=["planar-pair8-nt", "rowil-pair12-alt", "rowil-pair12-alt"], **kw)
+    parts = [c.macros() for c in ctxs]
+    for j in range(3):
+        assert np.array_equal(np.concatenate([p[j] for p in parts], axis=0), w[j])
+    assert np.array_equal(np.concatenate([c.populations("f_next")[1:-1] for c in ctxs], axis=0), w_fn[1:-1])
+    logs = [c.drain_force_log() for c in ctxs]
+    for k, (tt, fx, fy) in enumerate(w_log):
+        assert abs(sum(l[k][1] for l in logs) - fx) <= 1e-13 * max(1.0, abs(fx))
+    for c in ctxs:
+        c.close()
+
+
+def test_snapshot_refused_after_trailing_pair(lbm):
+    with lbm.Context(128, 32, options=dict(tune=0, pair=1, trailing_pair=1)) as ctx:
+        ctx.initialise()
+        ctx.step(2, 0)
+        with pytest.raises(lbm.LbmError, match="snapshot unavailable"):
+            ctx.macros()
+        ctx.step(1, 0)
+        ctx.macros()
+
+
 def test_fp32_variant_tracks_fp64(lbm):
     """BASELINE.json configs[4] is an fp32 variant the reference does not have: parity is against the fp64 result
     at an fp32-appropriate tolerance (stated: 2e-4 relative on rho and u after 1000 steps at 256x64)."""
     nx, ny, steps = 256, 64, 1000
     kw = dict(inlet_velocity=0.05)
     out = {}
-    for prec, plan in (("f64", None), ("f32", None), ("f32b", "rowil-vec-nt-alt"), ("f32c", "planar-site")):
+    for prec, plan in (("f64", None), ("f32", None), ("f32b", "rowil-vec-nt-alt"), ("f32c", "planar-site"),
+                       ("f32d", "planar-pair8-nt")):
         with lbm.Context(nx, ny, precision=prec[:3], options=PLANS[plan] if plan else None, **kw) as ctx:
             ctx.initialise()
             ctx.step(steps, 0)
@@ -230,7 +280,7 @@ def test_fp32_variant_tracks_fp64(lbm):
             out[prec] = ctx.macros()
     er, eu = macro_errors(*out["f32"], *out["f64"])
     assert er < 2e-4 and eu < 2e-4, (er, eu)
-    for other in ("f32b", "f32c"):       # every fp32 formulation is the same arithmetic: bit-identical
+    for other in ("f32b", "f32c", "f32d"):       # every fp32 formulation is the same arithmetic: bit-identical
         for a, b in zip(out["f32"], out[other]):
             assert np.array_equal(a, b)
 

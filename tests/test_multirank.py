@@ -76,7 +76,7 @@ def test_strips_over_gloo_cpu(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("backend", ["hip-host", "hip-rccl"])
+@pytest.mark.parametrize("backend", ["hip-host", "hip-host-pair", "hip-rccl"])
 def test_two_ranks_on_the_gpu(backend):
     """Two processes, two strips, both on device 0. hip-host: halos staged through the host over gloo. hip-rccl:
     the production RCCL send/recv path; RCCL may refuse two ranks on one device (then the test is skipped — the

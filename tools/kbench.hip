@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256) k_copy9(const KArgs<T> a) {
     const int x = (blockIdx.x * 256 + threadIdx.x) * VEC;
     const int y = blockIdx.y;
     if (x >= a.nx) return;
-    const long c = (long)(y + 1) * a.pitch + a.xoff + x;
+    const long c = (long)(y + GR) * a.pitch + a.xoff + x;
     typedef T VT __attribute__((ext_vector_type(VEC)));
     VT v[Q];
 #pragma unroll
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) k_site_opt(const KArgs<T> a) {
     if (REV && (a.t & 1)) y = a.ny_loc - 1 - y;
     if (x >= a.nx) return;
     const int yg = a.y_start + y;
-    const long c = (long)(y + 1) * a.pitch + a.xoff + x;
+    const long c = (long)(y + GR) * a.pitch + a.xoff + x;
     T f[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) k_site_vec(const KArgs<T> a) {
     if (REV && (a.t & 1)) y = a.ny_loc - 1 - y;
     if (x0 >= a.nx) return;   // (nx is a multiple of V in this tool)
     const int yg = a.y_start + y;
-    const long c = (long)(y + 1) * a.pitch + a.xoff + x0;
+    const long c = (long)(y + GR) * a.pitch + a.xoff + x0;
     VA fv[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
@@ -104,76 +104,6 @@ __global__ void __launch_bounds__(256) k_site_vec(const KArgs<T> a) {
 }
 
 
-// ---- two timesteps per launch (temporal blocking through LDS) ---------------------------------------------------
-// A block owns a TX x TY tile of outputs at step t+2. Phase 1 computes P_{t+1} for the (TX+2) x (TY+2) region around
-// it from global P_t (pull + BCs + collide, ghost/solid cells get their permanent constants) into LDS; phase 2
-// pulls from LDS, applies BCs, collides and stores P_{t+2}. HBM traffic per LUP: ~(1 + (TX+2)(TY+2)/(TX*TY)) * 36 B.
-template <typename T> struct K2Extra { T feq_in[Q]; };
-
-template <typename T, int TY, int NTH, bool NT>
-__global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Extra<T> e) {
-    constexpr int TX = 64, RW = TX + 2, RH = TY + 2, LP = RW + 2;
-    __shared__ T lds[Q][RH][LP];
-    const int X0 = blockIdx.x * TX;
-    int by = blockIdx.y;
-    if (a.reverse) by = gridDim.y - 1 - by;
-    const int Y0 = by * TY;
-    bool bad = false;
-    // phase 1
-    for (int r = threadIdx.x; r < RW * RH; r += NTH) {
-        const int ry = r / RW, rx = r - ry * RW;
-        const int x = X0 + rx - 1, y = Y0 + ry - 1;          // local coordinates, -1 .. nx / ny_loc
-        if (y > a.ny_loc) continue;                            // below-partial last tile: nothing there
-        const int yg = a.y_start + y;
-        const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
-        T f[Q];
-        if (!(row_in && col_in)) {
-#pragma unroll
-            for (int i = 0; i < Q; ++i) f[i] = (row_in && !col_in) ? T(0) : e.feq_in[i];
-        } else {
-            const long c = (long)(y + 1) * a.pitch + a.xoff + x;
-#pragma unroll
-            for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
-            const bool solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
-            T rho_bc, u_out;
-            if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
-            bad |= any_unstable(f);
-            if (solid) {
-#pragma unroll
-                for (int i = 0; i < Q; ++i) f[i] = wgt<T>(i);
-            } else bgk_collide(f, a.tau_inv);
-        }
-#pragma unroll
-        for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
-    }
-    if (bad) atomicMin(a.unstable_t, a.t);
-    __syncthreads();
-    // phase 2
-    bad = false;
-    for (int o = threadIdx.x; o < TX * TY; o += NTH) {
-        const int ly = o / TX, lx = o - ly * TX;
-        const int x = X0 + lx, y = Y0 + ly;
-        if (y >= a.ny_loc || x >= a.nx) continue;
-        const int yg = a.y_start + y;
-        T f[Q];
-#pragma unroll
-        for (int i = 0; i < Q; ++i) f[i] = lds[i][ly + 1 - cy(i)][lx + 1 - cx(i)];
-        const bool solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
-        T rho_bc, u_out;
-        if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
-        bad |= any_unstable(f);
-        if (solid) continue;
-        bgk_collide(f, a.tau_inv);
-        const long c = (long)(y + 1) * a.pitch + a.xoff + x;
-#pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            T* p = a.dst + (long)i * a.plane + c;
-            if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
-        }
-    }
-    if (bad) atomicMin(a.unstable_t, a.t + 1);
-}
-
 static long g_boff = 0;
 static bool g_single = false;
 static bool g_leak = false;
@@ -197,10 +127,10 @@ struct Bench {
         const int per128 = 128 / sizeof(T);
         xoff = per128;
         const int pitch0 = (xoff + nx + 1 + per128 - 1) / per128 * per128 + pitch_pad;
-        if (rowil) { plane = pitch0; rowstride = Q * pitch0 + (int)plane_pad_elems; total = (size_t)rowstride * (ny + 2); }
+        if (rowil) { plane = pitch0; rowstride = Q * pitch0 + (int)plane_pad_elems; total = (size_t)rowstride * (ny + 2 * GR); }
         else {
             rowstride = pitch0;
-            long raw = (long)pitch0 * (ny + 2);
+            long raw = (long)pitch0 * (ny + 2 * GR);
             if (plane_pad_elems < 0) {   // rule: plane stride = k*64 KiB + (-pad) bytes
                 const long w = 65536 / sizeof(T);
                 plane = (raw + w - 1) / w * w + (-plane_pad_elems) / (long)sizeof(T);
@@ -237,7 +167,7 @@ struct Bench {
         ia.feq_in[0] = (T)(wgt<double>(0) * (1.0 - 1.5 * usq));
         for (int i = 1; i < Q; ++i) { const double cu = cx(i) * ux; ia.feq_in[i] = (T)(wgt<double>(i) * (((1.0 + 3.0 * cu) - t3) + 4.5 * cu * cu)); }
         ia.solid_count = d_unst;
-        hipLaunchKernelGGL((k_init<T>), dim3((nx + 2 + 255) / 256, ny + 2), dim3(256), 0, s, ia);
+        hipLaunchKernelGGL((k_init<T>), dim3((nx + 2 + 255) / 256, ny + 2 * GR), dim3(256), 0, s, ia);
         const int big = 0x7fffffff;
         CK(hipMemcpyAsync(d_unst, &big, sizeof(int), hipMemcpyHostToDevice, s));
         CK(hipStreamSynchronize(s));
