@@ -79,6 +79,8 @@ struct lbm_ctx {
     int use_nt = 0;      // non-temporal stores in the step kernel
     int pair = 0;        // fuse two iterations per launch (k_step2_tile) where the schedule allows
     int pair_ty = 8;     // tile height of the two-step kernel (8 or 12)
+    int xcd = 0;         // two-step kernel: remap blocks so that each XCD walks a contiguous run of tiles
+    int loopback = 0;    // TEST ONLY: the strip is its own north and south neighbour (exercises the overlap choreography)
     int trailing_pair = 0;   // allow an lbm_step call to END on a fused launch (host-staged strips: nsteps == 2)
     bool last_was_pair = false;
     int tune = 1;        // lbm_initialise times the candidate plans on this device and keeps the fastest
@@ -174,13 +176,19 @@ void launch_pair_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
     for (int i = 0; i < Q; ++i) e.feq_in[i] = (T)c->feq_in[i];
     const int ty = c->pair_ty;
     dim3 grid(c->nx / 64, (a.y_cnt + ty - 1) / ty);
-    if (ty == 12) {
-        if (c->use_nt) hipLaunchKernelGGL((k_step2_tile<T, 12, 768, true>), grid, dim3(768), 0, s, a, e);
-        else hipLaunchKernelGGL((k_step2_tile<T, 12, 768, false>), grid, dim3(768), 0, s, a, e);
-    } else {
-        if (c->use_nt) hipLaunchKernelGGL((k_step2_tile<T, 8, 512, true>), grid, dim3(512), 0, s, a, e);
-        else hipLaunchKernelGGL((k_step2_tile<T, 8, 512, false>), grid, dim3(512), 0, s, a, e);
+#define LBM_K2(TY_, NTH_, NT_, X_) hipLaunchKernelGGL((k_step2_tile<T, TY_, NTH_, NT_, X_>), grid, dim3(NTH_), 0, s, a, e)
+    const int sel = (ty == 12 ? 4 : 0) + (c->use_nt ? 2 : 0) + (c->xcd ? 1 : 0);
+    switch (sel) {
+        case 0: LBM_K2(8, 512, false, false); break;
+        case 1: LBM_K2(8, 512, false, true); break;
+        case 2: LBM_K2(8, 512, true, false); break;
+        case 3: LBM_K2(8, 512, true, true); break;
+        case 4: LBM_K2(12, 768, false, false); break;
+        case 5: LBM_K2(12, 768, false, true); break;
+        case 6: LBM_K2(12, 768, true, false); break;
+        default: LBM_K2(12, 768, true, true); break;
     }
+#undef LBM_K2
 }
 inline bool pair_possible(const lbm_ctx* c) { return c->nx % 64 == 0; }
 
@@ -223,6 +231,14 @@ int launch_forces(lbm_ctx* c, double* out, int t) {
 // which GR rows x 9 sub-rows are ONE contiguous run of GR*pitch elements: one send + one recv per face, no packing.
 template <typename T>
 int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
+    if (c->loopback) {   // test transport: my own edge rows become my ghost rows (device copies on the same stream)
+        T* b = static_cast<T*>(c->buf[dst]);
+        if (c->layout != 1) return fail(LBM_ERR_COMM, "loopback requires the row-interleaved layout");
+        const size_t bytes = (size_t)GR * c->pitch * sizeof(T);
+        HIPCHK(hipMemcpyAsync(b, b + (long)c->nyl * c->pitch, bytes, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(b + (long)(c->nyl + GR) * c->pitch, b + (long)GR * c->pitch, bytes, hipMemcpyDeviceToDevice, s));
+        return LBM_OK;
+    }
     if (c->nranks <= 1) return LBM_OK;
     if (c->layout != 1) return fail(LBM_ERR_COMM, "strips require the row-interleaved layout");
     T* base = static_cast<T*>(c->buf[dst]);
@@ -257,7 +273,7 @@ int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
 template <typename T>
 int advance_with_exchange(lbm_ctx* c, int src, int dst, int t, bool pair) {
     KArgs<T> a = make_kargs<T>(c, src, dst, t);
-    const bool has_s = c->rank > 0, has_n = c->rank + 1 < c->nranks;
+    const bool has_s = c->rank > 0 || c->loopback, has_n = c->rank + 1 < c->nranks || c->loopback;
     auto launch = [&](int lo, int cnt, int reverse) {
         a.y_lo = lo; a.y_cnt = cnt; a.reverse = reverse;
         if (pair) launch_pair_rows<T>(c, a, c->stream);
@@ -362,11 +378,11 @@ inline int alloc_buffers(lbm_ctx* c) {
 // 4096x1024 fp64 depending on the allocation). All candidates compute bit-identical results, so lbm_initialise
 // times each one on the real buffers (8 warm-up + 24 timed launches, a few ms) and keeps the fastest together
 // with the very allocation it was measured on.
-struct Plan { int layout, variant, nt, alternate, pair, ty; const char* name; };
+struct Plan { int layout, variant, nt, alternate, pair, ty, xcd; const char* name; };
 
 inline void apply_plan(lbm_ctx* c, const Plan& pl) {
     configure_layout(c, pl.layout);
-    c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate; c->pair = pl.pair;
+    c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate; c->pair = pl.pair; c->xcd = pl.xcd;
     if (pl.ty) c->pair_ty = pl.ty;
 }
 
@@ -398,7 +414,8 @@ int time_plan(lbm_ctx* c, float* ms_out) {
 template <typename T>
 int choose_plan(lbm_ctx* c) {
     const bool strips = c->comm && c->nranks > 1;
-    const Plan fixed = {strips ? 1 : c->layout, c->variant, c->use_nt, c->alternate, c->pair, c->pair_ty, "fixed by options"};
+    const Plan fixed = {(strips || c->loopback) ? 1 : c->layout, c->variant, c->use_nt, c->alternate, c->pair, c->pair_ty, c->xcd,
+                        "fixed by options"};
     std::vector<Plan> cand;
     const bool vec_ok = (c->nx % vec_width<T>() == 0), p2 = pair_possible(c);
     size_t free_b = 0, total_b = 0;
@@ -409,21 +426,21 @@ int choose_plan(lbm_ctx* c) {
     const bool can_tune = c->tune && (size_t)c->nx * c->nyl >= (1u << 19) && 2 * need + (1u << 28) < free_b;
     if (!c->tune) cand.push_back(fixed);
     else if (!can_tune) {
-        if (strips) cand.push_back({1, 1, 0, 1, p2 ? 1 : 0, 8, "row-interleaved (default, not measured)"});
-        else cand.push_back({0, vec_ok ? 0 : 1, 0, 1, p2 ? 1 : 0, 8, "planar (default, not measured)"});
+        if (strips) cand.push_back({1, 1, 0, 1, p2 ? 1 : 0, 8, 1, "row-interleaved (default, not measured)"});
+        else cand.push_back({0, vec_ok ? 0 : 1, 0, 1, p2 ? 1 : 0, 8, 0, "planar (default, not measured)"});
     } else {
         // strips exchange GR rows x 9 sub-rows as one contiguous run: row-interleaved only
-        if (p2) cand.push_back({1, 1, 1, 0, 1, 8, "row-interleaved/2-step 64x8/nt-store"});
-        if (p2) cand.push_back({1, 1, 1, 0, 1, 12, "row-interleaved/2-step 64x12/nt-store"});
-        if (p2) cand.push_back({1, 1, 0, 1, 1, 8, "row-interleaved/2-step 64x8/alternate"});
-        cand.push_back({1, 1, 1, 0, 0, 0, "row-interleaved/site/nt-store"});
-        cand.push_back({1, 1, 0, 1, 0, 0, "row-interleaved/site/alternate"});
+        if (p2) cand.push_back({1, 1, 1, 0, 1, 8, 1, "row-interleaved/2-step 64x8/nt-store/xcd"});
+        if (p2) cand.push_back({1, 1, 1, 0, 1, 12, 1, "row-interleaved/2-step 64x12/nt-store/xcd"});
+        if (p2) cand.push_back({1, 1, 0, 1, 1, 8, 1, "row-interleaved/2-step 64x8/alternate/xcd"});
+        cand.push_back({1, 1, 1, 0, 0, 0, 0, "row-interleaved/site/nt-store"});
+        cand.push_back({1, 1, 0, 1, 0, 0, 0, "row-interleaved/site/alternate"});
         if (!strips) {
-            if (p2) cand.push_back({0, 0, 1, 0, 1, 8, "planar/2-step 64x8/nt-store"});
-            if (p2) cand.push_back({0, 0, 1, 0, 1, 12, "planar/2-step 64x12/nt-store"});
-            if (p2) cand.push_back({0, 0, 0, 1, 1, 8, "planar/2-step 64x8/alternate"});
-            if (vec_ok) cand.push_back({0, 0, 0, 1, 0, 0, "planar/vec16B/alternate"});
-            cand.push_back({0, 1, 0, 1, 0, 0, "planar/site/alternate"});
+            if (p2) cand.push_back({0, 0, 1, 0, 1, 8, 0, "planar/2-step 64x8/nt-store"});
+            if (p2) cand.push_back({0, 0, 1, 0, 1, 12, 0, "planar/2-step 64x12/nt-store"});
+            if (p2) cand.push_back({0, 0, 0, 1, 1, 8, 0, "planar/2-step 64x8/alternate"});
+            if (vec_ok) cand.push_back({0, 0, 0, 1, 0, 0, 0, "planar/vec16B/alternate"});
+            cand.push_back({0, 1, 0, 1, 0, 0, 0, "planar/site/alternate"});
         }
     }
     void* best_buf[2] = {nullptr, nullptr};
@@ -465,7 +482,7 @@ int do_initialise(lbm_ctx* c) {
     HIPCHK(hipMemcpyAsync(c->d_unstable, &big, sizeof(int), hipMemcpyHostToDevice, c->stream));
     rc = init_state<T>(c);
     if (rc) return rc;
-    if (c->comm) {
+    if (c->comm || c->loopback) {
         rc = exchange_rccl<T>(c, c->cur, c->stream);
         if (rc) return rc;
     }
@@ -475,7 +492,7 @@ int do_initialise(lbm_ctx* c) {
 template <typename T>
 int do_steps(lbm_ctx* c, int nsteps, int of) {
     if (c->timing) HIPCHK(hipEventRecord(c->ev_t0, c->stream));
-    const bool exchange = c->comm && c->nranks > 1;
+    const bool exchange = (c->comm && c->nranks > 1) || c->loopback;
     int launches = 0;
     for (int k = 0; k < nsteps;) {
         const int t = c->steps_done;
@@ -858,7 +875,7 @@ int lbm_halo_import(lbm_ctx* c, const double* south_in, const double* north_in) 
 int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     if (!c || !key) return fail(LBM_ERR_ARG, "null argument");
     const std::string k(key);
-    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune" || k == "pair" || k == "pair_ty"))
+    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune" || k == "pair" || k == "pair_ty" || k == "loopback"))
         return fail(LBM_ERR_ARG, "option %s must be set before lbm_initialise", key);
     if (k == "variant") c->variant = (int)value;
     else if (k == "timing") c->timing = (int)value;
@@ -867,6 +884,8 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "nt") c->use_nt = (int)value ? 1 : 0;
     else if (k == "pair") c->pair = (int)value ? 1 : 0;
     else if (k == "trailing_pair") c->trailing_pair = (int)value ? 1 : 0;
+    else if (k == "xcd") c->xcd = (int)value ? 1 : 0;
+    else if (k == "loopback") c->loopback = (int)value ? 1 : 0;
     else if (k == "pair_ty") { if (value != 8 && value != 12) return fail(LBM_ERR_ARG, "pair_ty must be 8 or 12"); c->pair_ty = (int)value; }
     else if (k == "tune") c->tune = (int)value ? 1 : 0;
     else if (k == "overlap") c->overlap = (int)value;
@@ -905,7 +924,7 @@ const char* lbm_kernel_name(const lbm_ctx* c) {
     static thread_local char name[96];
     const char* t = c->p.precision == LBM_PRECISION_F32 ? "float" : "double";
     const char* nt = c->use_nt ? "true" : "false";
-    if (c->pair && pair_possible(c)) snprintf(name, sizeof(name), "k_step2_tile<%s,%d,%d,%s>", t, c->pair_ty, c->pair_ty == 12 ? 768 : 512, nt);
+    if (c->pair && pair_possible(c)) snprintf(name, sizeof(name), "k_step2_tile<%s,%d,%d,%s,%s>", t, c->pair_ty, c->pair_ty == 12 ? 768 : 512, nt, c->xcd ? "true" : "false");
     else if (use_vec(c)) snprintf(name, sizeof(name), "k_step_vec<%s,%d,0,%s>", t, (int)(16 / c->esize), nt);
     else snprintf(name, sizeof(name), "k_step_site<%s,0,%s>", t, nt);
     return name;

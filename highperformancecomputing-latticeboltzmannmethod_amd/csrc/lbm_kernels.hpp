@@ -256,12 +256,22 @@ __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
 // present two deep (GR = 2). LDS: 9*(TY+2)*(TX+4)*sizeof(T) (47.9 KB at TY=8, fp64: three blocks per CU).
 template <typename T> struct K2Extra { T feq_in[Q]; };
 
-template <typename T, int TY, int NTH, bool NT>
+template <typename T, int TY, int NTH, bool NT, bool XCD = false>
 __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int TX = 64, RW = TX + 2, RH = TY + 2, LP = RW + 2;
     __shared__ T lds[Q][RH][LP];
-    const int X0 = blockIdx.x * TX;
-    const int by = a.reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+    // Tile of this block. Workgroups are dealt round-robin over the 8 XCDs (each with its own L2); with XCD the
+    // linear block id is remapped so that every XCD walks one contiguous run of tiles: horizontally adjacent tiles,
+    // which share the cache lines at their common edge, then run on the same L2 at the same time.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (XCD) {
+        const int nb = gridDim.x * gridDim.y;
+        int b = by * gridDim.x + bx;
+        if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;
+        by = b / gridDim.x; bx = b - by * gridDim.x;
+    }
+    if (a.reverse) by = (int)gridDim.y - 1 - by;
+    const int X0 = bx * TX;
     const int Y0 = a.y_lo + by * TY;
     const int y_end = a.y_lo + a.y_cnt;                        // rows >= y_end belong to another launch
     bool bad = false;

@@ -35,7 +35,7 @@ PLANS = {
     "rowil-vec-nt-alt": dict(tune=0, layout=1, variant=0, nt=1, alternate=1),
     # two iterations fused per launch through LDS (k_step2_tile; falls back to one per launch when nx % 64 != 0)
     "planar-pair8-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, pair=1, pair_ty=8),
-    "rowil-pair12-alt": dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair=1, pair_ty=12),
+    "rowil-pair12-alt": dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair=1, pair_ty=12, xcd=1),
 }
 
 
@@ -253,6 +253,25 @@ def test_strips_with_fused_pairs_match_single_domain_bitwise(lbm):
         assert abs(sum(l[k][1] for l in logs) - fx) <= 1e-13 * max(1.0, abs(fx))
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("pair", [0, 1])
+def test_overlap_choreography_with_loopback_halo(lbm, pair):
+    """The strip step as it runs under RCCL — edge rows first, exchange on the side stream, interior rows overlapped,
+    two events — with the test-only loopback transport (the strip is its own neighbour: device copies instead of
+    ncclSend/ncclRecv). Overlapped and serialised schedules must agree bit for bit over many launches."""
+    nx, ny, steps = 1024, 96, 301
+    kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
+    out = []
+    for overlap in (0, 1):
+        with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, pair=pair, xcd=1, loopback=1,
+                                              overlap=overlap), **kw) as ctx:
+            ctx.initialise()
+            ctx.step(steps, 50)
+            ctx.sync()
+            out.append((ctx.populations("f_next"), ctx.drain_force_log(), ctx.first_unstable_step()))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
 
 
 def test_snapshot_refused_after_trailing_pair(lbm):

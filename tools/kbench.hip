@@ -224,6 +224,13 @@ void suite(int nx, int ny, long pad, int reps, int rounds, bool rowil, int pitch
         vars.push_back({"step2 TY4 384t", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 4, 384, false>), g2(4), dim3(384), 0, s, a, ex); }, {}});
         vars.push_back({"step2 TY12 768t", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 12, 768, false>), g2(12), dim3(768), 0, s, a, ex); }, {}});
         vars.push_back({"step2 TY16 1024t", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 16, 1024, false>), g2(16), dim3(1024), 0, s, a, ex); }, {}});
+        vars.push_back({"step2 TY12 768t nt", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 12, 768, true>), g2(12), dim3(768), 0, s, a, ex); }, {}});
+        vars.push_back({"step2 TY12 768t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 12, 768, true, true>), g2(12), dim3(768), 0, s, a, ex); }, {}});
+        vars.push_back({"step2 TY8 512t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 8, 512, true, true>), g2(8), dim3(512), 0, s, a, ex); }, {}});
+        vars.push_back({"step2 TY14 896t nt", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 14, 896, true>), g2(14), dim3(896), 0, s, a, ex); }, {}});
+        vars.push_back({"step2 TY14 896t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 14, 896, true, true>), g2(14), dim3(896), 0, s, a, ex); }, {}});
+        vars.push_back({"step2 TY14 448t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 14, 448, true, true>), g2(14), dim3(448), 0, s, a, ex); }, {}});
+        vars.push_back({"step2 TY12 384t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 12, 384, true, true>), g2(12), dim3(384), 0, s, a, ex); }, {}});
         vars.push_back({"step2 TY16 1024t nt", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 16, 1024, true>), g2(16), dim3(1024), 0, s, a, ex); }, {}});
     }
     if (g_check) {   // step2 variants: 6 launches must equal 12 single steps, bit for bit
