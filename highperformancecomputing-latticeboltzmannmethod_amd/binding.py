@@ -61,6 +61,8 @@ def lib():
         L.lbm_halo_export.argtypes = [vp, dp, dp]
         L.lbm_halo_import.argtypes = [vp, dp, dp]
         L.lbm_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+        L.lbm_save_state.argtypes = [vp, C.c_char_p]
+        L.lbm_load_state.argtypes = [vp, C.c_char_p]
         L.lbm_last_step_kernel_ms.argtypes = [vp, dp]
         L.lbm_last_step_stats.argtypes = [vp, dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.lbm_kernel_name.argtypes = [vp]; L.lbm_kernel_name.restype = C.c_char_p
@@ -201,6 +203,12 @@ class Context:
         s = np.ascontiguousarray(south, dtype=np.float64) if south is not None else None
         n = np.ascontiguousarray(north, dtype=np.float64) if north is not None else None
         self._chk(self.L.lbm_halo_import(self.h, _dp(s), _dp(n)))
+
+    def save_state(self, path):
+        self._chk(self.L.lbm_save_state(self.h, os.fspath(path).encode()))
+
+    def load_state(self, path):
+        self._chk(self.L.lbm_load_state(self.h, os.fspath(path).encode()))
 
     def last_step_stats(self):
         """(device ms of the last step() call, step-kernel launches it issued, iterations it advanced)."""

@@ -83,6 +83,7 @@ struct lbm_ctx {
     int loopback = 0;    // TEST ONLY: the strip is its own north and south neighbour (exercises the overlap choreography)
     int trailing_pair = 0;   // allow an lbm_step call to END on a fused launch (host-staged strips: nsteps == 2)
     bool last_was_pair = false;
+    bool restored = false;   // state came from lbm_load_state: no previous-iteration buffer until the next step
     int tune = 1;        // lbm_initialise times the candidate plans on this device and keeps the fastest
     char plan_desc[160] = "";
     int timing = 0;
@@ -329,6 +330,7 @@ int advance(lbm_ctx* c, int remaining, int of, bool exchange) {
     c->steps_done = t + (pair ? 2 : 1);
     c->launches_total++;
     c->last_was_pair = pair;
+    c->restored = false;
     return pair ? 2 : 1;
 }
 
@@ -607,6 +609,51 @@ int do_halo_import(lbm_ctx* c, const double* south_in, const double* north_in) {
 
 }  // namespace
 
+// ---- checkpoint / restart (the reference keeps its state in memory only) ------------------------
+// File: header {magic "LBMCKPT1", nx, ny, y_start, local_ny, precision, steps_done, tau, inlet_velocity, cylinder_*}
+// followed by the post-collision populations P_{steps_done} of the strip's interior, [9][local_ny][nx] in the
+// element type. The state is complete: ghost cells and solid cells are reconstructed by lbm_initialise.
+namespace {
+struct CkptHeader {
+    char magic[8];
+    int nx, ny, y_start, local_ny, precision, steps_done;
+    double tau, inlet_velocity, cylinder_x, cylinder_y, cylinder_radius;
+};
+
+template <typename T>
+int do_save(lbm_ctx* c, FILE* fp) {
+    std::vector<T> row((size_t)c->nx);
+    std::vector<T> host(c->total);
+    HIPCHK(hipMemcpyAsync(host.data(), c->buf[c->cur], c->total * c->esize, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < Q; ++i)
+        for (int y = 0; y < c->nyl; ++y) {
+            const T* src = host.data() + (size_t)i * c->plane + (size_t)(y + GR) * c->pitch + c->xoff;
+            if (fwrite(src, sizeof(T), (size_t)c->nx, fp) != (size_t)c->nx) return fail(LBM_ERR_ARG, "short write");
+        }
+    return LBM_OK;
+}
+
+template <typename T>
+int do_load(lbm_ctx* c, FILE* fp, int steps_done) {
+    // buf[cur] already holds P_0 with all ghost/solid constants in place: overwrite the interior, then rebuild the
+    // previous-iteration buffer's ghost frame is not needed (it is only read by snapshots after the next step).
+    std::vector<T> host(c->total);
+    HIPCHK(hipMemcpyAsync(host.data(), c->buf[c->cur], c->total * c->esize, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < Q; ++i)
+        for (int y = 0; y < c->nyl; ++y) {
+            T* dst = host.data() + (size_t)i * c->plane + (size_t)(y + GR) * c->pitch + c->xoff;
+            if (fread(dst, sizeof(T), (size_t)c->nx, fp) != (size_t)c->nx) return fail(LBM_ERR_ARG, "short read");
+        }
+    HIPCHK(hipMemcpyAsync(c->buf[c->cur], host.data(), c->total * c->esize, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->steps_done = steps_done;
+    c->restored = true;
+    return LBM_OK;
+}
+}  // namespace
+
 extern "C" {
 
 const char* lbm_last_error(void) { return g_err; }
@@ -778,7 +825,7 @@ int lbm_drain_force_log(lbm_ctx* c, lbm_force_row* rows, int max_rows) {
 
 int lbm_get_macros(lbm_ctx* c, double* rho, double* ux, double* uy) {
     if (!c || !c->initialised) return fail(LBM_ERR_ARG, "context not initialised");
-    if (c->last_was_pair) return fail(LBM_ERR_ARG, "snapshot unavailable: the last launch fused two iterations (trailing_pair); take one more lbm_step(c,1,..)");
+    if (c->last_was_pair || c->restored) return fail(LBM_ERR_ARG, "snapshot unavailable: the previous iteration's populations are not resident (fused trailing launch or restored state); take one more lbm_step(c,1,..)");
     HIPCHK(hipSetDevice(c->device));
     { int jr = join_comm(c); if (jr) return jr; }
     int rc = DISPATCH(c, do_macros<double>(c, false), do_macros<float>(c, false));
@@ -793,7 +840,7 @@ int lbm_get_macros(lbm_ctx* c, double* rho, double* ux, double* uy) {
 
 int lbm_max_velocity_sq(lbm_ctx* c, double* out) {
     if (!c || !c->initialised || !out) return fail(LBM_ERR_ARG, "bad argument");
-    if (c->last_was_pair) return fail(LBM_ERR_ARG, "snapshot unavailable: the last launch fused two iterations (trailing_pair); take one more lbm_step(c,1,..)");
+    if (c->last_was_pair || c->restored) return fail(LBM_ERR_ARG, "snapshot unavailable: the previous iteration's populations are not resident (fused trailing launch or restored state); take one more lbm_step(c,1,..)");
     HIPCHK(hipSetDevice(c->device));
     { int jr = join_comm(c); if (jr) return jr; }
     int rc = DISPATCH(c, do_macros<double>(c, true), do_macros<float>(c, true));
@@ -807,7 +854,7 @@ int lbm_max_velocity_sq(lbm_ctx* c, double* out) {
 
 int lbm_get_populations(lbm_ctx* c, int which, double* aos) {
     if (!c || !c->initialised || !aos || (which != 0 && which != 1)) return fail(LBM_ERR_ARG, "bad argument");
-    if (c->last_was_pair) return fail(LBM_ERR_ARG, "snapshot unavailable: the last launch fused two iterations (trailing_pair); take one more lbm_step(c,1,..)");
+    if (c->last_was_pair || c->restored) return fail(LBM_ERR_ARG, "snapshot unavailable: the previous iteration's populations are not resident (fused trailing launch or restored state); take one more lbm_step(c,1,..)");
     HIPCHK(hipSetDevice(c->device));
     { int jr = join_comm(c); if (jr) return jr; }
     return DISPATCH(c, do_populations<double>(c, which, aos), do_populations<float>(c, which, aos));
@@ -870,6 +917,44 @@ int lbm_halo_import(lbm_ctx* c, const double* south_in, const double* north_in) 
     HIPCHK(hipSetDevice(c->device));
     { int jr = join_comm(c); if (jr) return jr; }
     return DISPATCH(c, do_halo_import<double>(c, south_in, north_in), do_halo_import<float>(c, south_in, north_in));
+}
+
+int lbm_save_state(lbm_ctx* c, const char* path) {
+    if (!c || !c->initialised || !path) return fail(LBM_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    { int jr = join_comm(c); if (jr) return jr; }
+    FILE* fp = fopen(path, "wb");
+    if (!fp) return fail(LBM_ERR_ARG, "cannot open %s for writing", path);
+    CkptHeader h{};
+    memcpy(h.magic, "LBMCKPT1", 8);
+    h.nx = c->nx; h.ny = c->p.ny; h.y_start = c->p.y_start; h.local_ny = c->nyl; h.precision = c->p.precision;
+    h.steps_done = c->steps_done; h.tau = c->p.tau; h.inlet_velocity = c->p.inlet_velocity;
+    h.cylinder_x = c->p.cylinder_x; h.cylinder_y = c->p.cylinder_y; h.cylinder_radius = c->p.cylinder_radius;
+    int rc = fwrite(&h, sizeof(h), 1, fp) == 1 ? LBM_OK : fail(LBM_ERR_ARG, "short write");
+    if (!rc) rc = DISPATCH(c, do_save<double>(c, fp), do_save<float>(c, fp));
+    fclose(fp);
+    return rc;
+}
+
+int lbm_load_state(lbm_ctx* c, const char* path) {
+    if (!c || !c->initialised || !path) return fail(LBM_ERR_ARG, "lbm_load_state needs an initialised context");
+    HIPCHK(hipSetDevice(c->device));
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return fail(LBM_ERR_ARG, "cannot open %s", path);
+    CkptHeader h{};
+    int rc = LBM_OK;
+    if (fread(&h, sizeof(h), 1, fp) != 1 || memcmp(h.magic, "LBMCKPT1", 8) != 0) rc = fail(LBM_ERR_ARG, "%s is not a checkpoint", path);
+    else if (h.nx != c->nx || h.ny != c->p.ny || h.y_start != c->p.y_start || h.local_ny != c->nyl ||
+             h.precision != c->p.precision || h.tau != c->p.tau || h.inlet_velocity != c->p.inlet_velocity ||
+             h.cylinder_x != c->p.cylinder_x || h.cylinder_y != c->p.cylinder_y || h.cylinder_radius != c->p.cylinder_radius)
+        rc = fail(LBM_ERR_ARG, "checkpoint %s was written for different parameters", path);
+    if (!rc) rc = DISPATCH(c, do_load<double>(c, fp, h.steps_done), do_load<float>(c, fp, h.steps_done));
+    fclose(fp);
+    if (rc) return rc;
+    c->log_count = 0;
+    c->last_was_pair = false;
+    if (c->comm || c->loopback) rc = DISPATCH(c, exchange_rccl<double>(c, c->cur, c->stream), exchange_rccl<float>(c, c->cur, c->stream));
+    return rc;
 }
 
 int lbm_set_option(lbm_ctx* c, const char* key, long value) {

@@ -98,6 +98,12 @@ public:
         rows.resize(n);
         return rows;
     }
+    // checkpoint / restart (build-only feature; the reference keeps its state in memory only)
+    void save_state(const std::string& path) const { check(lbm_save_state(ctx_, path.c_str()), "lbm_save_state"); }
+    void load_state(const std::string& path) {
+        check(lbm_load_state(ctx_, path.c_str()), "lbm_load_state");
+        invalidate();
+    }
     const char* plan() const { return lbm_plan(ctx_); }
     lbm_ctx* handle() const { return ctx_; }
 

@@ -73,6 +73,10 @@ public:
         return true;
     }
 
+    // Restart support: continue a run from a state written by save_state (same parameters).
+    void load_state(const std::string& path) { grid_.load_state(path); }
+    void save_state(const std::string& path) const { grid_.save_state(path); }
+
     const Grid& get_grid() const { return grid_; }
     const SimulationParams& get_params() const { return params_; }
 

@@ -15,6 +15,7 @@ static void usage() {
     std::puts("lbm_solver [--nx N] [--ny N] [--steps N] [--output-frequency N] [--tau X] [--inlet-velocity X]\n"
               "           [--reynolds RE] [--cylinder-x F] [--cylinder-y F] [--cylinder-radius F] [--vtk-start-step N]\n"
               "           [--no-vtk] [--no-final] [--sync-vtk] [--fp32] [--no-tune] [--device D] [--quiet]\n"
+              "           [--checkpoint FILE] [--restart FILE]\n"
               "Defaults are the reference's SimulationParams (LBMConfig.h:37-51). --reynolds sets the inlet velocity\n"
               "from tau and the cylinder diameter so that params.reynolds() equals RE.");
 }
@@ -23,6 +24,7 @@ int main(int argc, char** argv) {
     LBM::SimulationParams params;
     LBM::BackendOptions opt;
     bool vtk = true, final_results = true;
+    std::string restart_from, checkpoint_to;
     double reynolds = -1.0;
     for (int a = 1; a < argc; ++a) {
         const std::string k = argv[a];
@@ -48,6 +50,8 @@ int main(int argc, char** argv) {
         else if (k == "--no-tune") opt.tune = false;
         else if (k == "--device") opt.device = std::atoi(val());
         else if (k == "--quiet") opt.quiet = true;
+        else if (k == "--restart") restart_from = val();
+        else if (k == "--checkpoint") checkpoint_to = val();
         else if (k == "--help" || k == "-h") { usage(); return 0; }
         else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); usage(); return 2; }
     }
@@ -56,7 +60,9 @@ int main(int argc, char** argv) {
         LBM::Solver solver(params, vtk, opt);
         LBM::IOManager io_manager;
         solver.initialise();
+        if (!restart_from.empty()) solver.load_state(restart_from);   // continues at the saved iteration
         const bool success = solver.run(io_manager);
+        if (success && !checkpoint_to.empty()) solver.save_state(checkpoint_to);
         if (success) {
             if (final_results) io_manager.write_final_results(solver.get_grid(), solver.get_params());
             std::printf("\nSimulation completed successfully!\n");

@@ -118,6 +118,12 @@ int  lbm_comm_allreduce(lbm_ctx* c, double* vals, int n, int op);
 int  lbm_halo_export(lbm_ctx* c, double* south_out, double* north_out);
 int  lbm_halo_import(lbm_ctx* c, const double* south_in, const double* north_in);
 
+/* Checkpoint / restart (the reference has none): the strip's post-collision populations and the
+ * iteration counter. lbm_load_state needs an initialised context created with the same parameters; the macro /
+ * population snapshots become available again after the next lbm_step. */
+int  lbm_save_state(lbm_ctx* c, const char* path);
+int  lbm_load_state(lbm_ctx* c, const char* path);
+
 /* Tuning/diagnostics (not part of the reference surface). Keys, all to be set before lbm_initialise:
  *   "tune" 1|0    time the candidate plans at lbm_initialise and keep the fastest (default 1); with 0 the plan is
  *                 "layout" 0 planar|1 row-interleaved, "variant" 0 16-B-per-lane kernel|1 one site per thread,

@@ -274,6 +274,56 @@ def test_overlap_choreography_with_loopback_halo(lbm, pair):
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
 
 
+def test_checkpoint_restart_is_bit_exact(lbm, tmp_path):
+    """Save at iteration 137, restore into a fresh context (different plan), continue: identical to the uninterrupted run."""
+    nx, ny = 256, 96
+    kw = dict(inlet_velocity=0.07, cylinder_radius=0.1)
+    with lbm.Context(nx, ny, options=PLANS["planar-pair8-nt"], **kw) as a:
+        a.initialise()
+        a.step(137, 0)
+        a.save_state(tmp_path / "s.ckpt")
+        a.step(200, 50)
+        ref = (a.macros(), a.populations("f_next"), a.drain_force_log())
+    with lbm.Context(nx, ny, options=PLANS["rowil-site-nt"], **kw) as b:
+        b.initialise()
+        b.load_state(tmp_path / "s.ckpt")
+        assert b.steps_done == 137
+        with pytest.raises(lbm.LbmError, match="snapshot unavailable"):
+            b.macros()
+        b.step(200, 50)
+        got = (b.macros(), b.populations("f_next"), b.drain_force_log())
+    for u, v in zip(ref[0], got[0]):
+        assert np.array_equal(u, v)
+    assert np.array_equal(ref[1], got[1]) and ref[2] == got[2]
+    with lbm.Context(nx, ny, inlet_velocity=0.08, cylinder_radius=0.1) as c:
+        c.initialise()
+        with pytest.raises(lbm.LbmError, match="different parameters"):
+            c.load_state(tmp_path / "s.ckpt")
+
+
+def test_c4_grid_8192x2048_single_gpu(lbm):
+    """BASELINE.json configs[3] grid (8192x2048, Re=200) on ONE GPU (the 8-GPU strip run belongs to the driver):
+    bit-exact populations against the oracle over a bounded window, and decomposition invariance for 8 strips."""
+    from oracle.oracle import Oracle, make_params
+    nx, ny, steps = 8192, 2048, 12
+    kw = dict(inlet_velocity=0.03255208)
+    o = Oracle(make_params(nx, ny, **kw))
+    assert o.run(steps) == -1 and o.solid_count() == 32681
+    with lbm.Context(nx, ny, **kw) as ctx:
+        assert ctx.initialise() == 32681
+        ctx.step(steps, 0)
+        assert np.array_equal(ctx.populations("f_next"), o.f_next)
+        w = ctx.macros()
+    o.close()
+    ctxs, _ = _run_strips(lbm, nx, ny, lbm.partition_rows(ny, 8), steps, 0, pairs=True,
+                          plans=["rowil-pair12-alt"] * 8, **kw)
+    parts = [c.macros() for c in ctxs]
+    for j in range(3):
+        assert np.array_equal(np.concatenate([p[j] for p in parts], axis=0), w[j])
+    for c in ctxs:
+        c.close()
+
+
 def test_snapshot_refused_after_trailing_pair(lbm):
     with lbm.Context(128, 32, options=dict(tune=0, pair=1, trailing_pair=1)) as ctx:
         ctx.initialise()

@@ -70,3 +70,20 @@ def test_lbm_solver_reports_instability_like_the_reference():
     assert "LBM simulation failed." in pr.stderr
     rows = open(os.path.join(d, "forces.csv")).read().splitlines()[1:]
     assert [int(r.split(",")[0]) for r in rows] == [0, 50]      # record_forces ran at t=0 and t=50 (< 74)
+
+
+@pytest.mark.gpu
+def test_lbm_solver_checkpoint_restart_continues_bit_exactly():
+    """--checkpoint after 600 iterations, --restart to 1201: forces rows and final field equal the uninterrupted run."""
+    g = load_golden("g9_files_64x32_s1201")
+    base = ["--nx", "64", "--ny", "32", "--output-frequency", "400", "--inlet-velocity", "0.04", "--cylinder-radius", "0.1",
+            "--no-vtk", "--quiet"]
+    d = tempfile.mkdtemp(prefix="lbm_host_")
+    subprocess.run([EXE] + base + ["--steps", "600", "--checkpoint", "s.ckpt", "--no-final"], cwd=d, check=True, timeout=300,
+                   stdout=subprocess.DEVNULL)
+    subprocess.run([EXE] + base + ["--steps", "1201", "--restart", "s.ckpt"], cwd=d, check=True, timeout=300,
+                   stdout=subprocess.DEVNULL)
+    same_text(open(os.path.join(d, "velocity_field.csv")).read(), bytes(g["velocity_field_csv"]).decode())
+    ours = open(os.path.join(d, "forces.csv")).read().splitlines()
+    ref = bytes(g["forces_csv"]).decode().splitlines()
+    same_text("\n".join(ours[1:]), "\n".join(ref[3:]))      # the restarted run records t = 800 and 1200
