@@ -77,9 +77,9 @@ struct lbm_ctx {
     int variant = 0;     // 0: k_step_vec when nx % V == 0; 1: k_step_site
     int alternate = 1;   // walk the rows bottom-up / top-down on alternate steps (Infinity Cache reuse)
     int use_nt = 0;      // non-temporal stores in the step kernel
-    int pair = 0;        // fuse two iterations per launch (k_step2_tile) where the schedule allows
-    int pair_ty = 8;     // tile height of the two-step kernel (8 or 12)
-    int xcd = 0;         // two-step kernel: remap blocks so that each XCD walks a contiguous run of tiles
+    int fuse = 1;        // iterations fused per launch where the schedule allows: 1, 2 (k_step2_tile) or 3 (k_step3_tile)
+    int pair_ty = 8;     // tile height of the fused kernels (8 or 12)
+    int xcd = 0;         // fused kernels: remap blocks so that each XCD walks a contiguous run of tiles
     int loopback = 0;    // TEST ONLY: the strip is its own north and south neighbour (exercises the overlap choreography)
     int trailing_pair = 0;   // allow an lbm_step call to END on a fused launch (host-staged strips: nsteps == 2)
     bool last_was_pair = false;
@@ -170,36 +170,52 @@ void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
     }
 }
 
-// The two-step kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt): iterations a.t and a.t + 1.
+// A fused kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt): iterations a.t .. a.t + depth - 1 (depth 2 or 3).
 template <typename T>
-void launch_pair_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
+void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s) {
     K2Extra<T> e;
     for (int i = 0; i < Q; ++i) e.feq_in[i] = (T)c->feq_in[i];
     const int ty = c->pair_ty;
     dim3 grid(c->nx / 64, (a.y_cnt + ty - 1) / ty);
 #define LBM_K2(TY_, NTH_, NT_, X_) hipLaunchKernelGGL((k_step2_tile<T, TY_, NTH_, NT_, X_>), grid, dim3(NTH_), 0, s, a, e)
+#define LBM_K3(TY_, NTH_, NT_, X_) hipLaunchKernelGGL((k_step3_tile<T, TY_, NTH_, NT_, X_>), grid, dim3(NTH_), 0, s, a, e)
     const int sel = (ty == 12 ? 4 : 0) + (c->use_nt ? 2 : 0) + (c->xcd ? 1 : 0);
-    switch (sel) {
-        case 0: LBM_K2(8, 512, false, false); break;
-        case 1: LBM_K2(8, 512, false, true); break;
-        case 2: LBM_K2(8, 512, true, false); break;
-        case 3: LBM_K2(8, 512, true, true); break;
-        case 4: LBM_K2(12, 768, false, false); break;
-        case 5: LBM_K2(12, 768, false, true); break;
-        case 6: LBM_K2(12, 768, true, false); break;
-        default: LBM_K2(12, 768, true, true); break;
+    if (depth == 3) {
+        switch (sel) {
+            case 0: LBM_K3(8, 512, false, false); break;
+            case 1: LBM_K3(8, 512, false, true); break;
+            case 2: LBM_K3(8, 512, true, false); break;
+            case 3: LBM_K3(8, 512, true, true); break;
+            case 4: LBM_K3(12, 768, false, false); break;
+            case 5: LBM_K3(12, 768, false, true); break;
+            case 6: LBM_K3(12, 768, true, false); break;
+            default: LBM_K3(12, 768, true, true); break;
+        }
+    } else {
+        switch (sel) {
+            case 0: LBM_K2(8, 512, false, false); break;
+            case 1: LBM_K2(8, 512, false, true); break;
+            case 2: LBM_K2(8, 512, true, false); break;
+            case 3: LBM_K2(8, 512, true, true); break;
+            case 4: LBM_K2(12, 768, false, false); break;
+            case 5: LBM_K2(12, 768, false, true); break;
+            case 6: LBM_K2(12, 768, true, false); break;
+            default: LBM_K2(12, 768, true, true); break;
+        }
     }
 #undef LBM_K2
+#undef LBM_K3
 }
 inline bool pair_possible(const lbm_ctx* c) { return c->nx % 64 == 0; }
 
 template <typename T>
 int launch_step(lbm_ctx* c, int src, int dst, int t, int mode, hipStream_t s) {
     KArgs<T> a = make_kargs<T>(c, src, dst, t);
-    a.reverse = ((mode == MODE_STEP || mode == 100) && c->alternate && (c->launches_total & 1)) ? 1 : 0;
+    a.reverse = ((mode == MODE_STEP || mode >= 100) && c->alternate && (c->launches_total & 1)) ? 1 : 0;
     switch (mode) {
         case MODE_STEP: launch_rows<T, MODE_STEP>(c, a, s); break;
-        case 100: launch_pair_rows<T>(c, a, s); break;     // two iterations: t and t+1
+        case 102: launch_fused_rows<T>(c, a, 2, s); break;     // iterations t, t+1
+        case 103: launch_fused_rows<T>(c, a, 3, s); break;     // iterations t, t+1, t+2
         case MODE_COLLIDE_ONLY: launch_rows<T, MODE_COLLIDE_ONLY>(c, a, s); break;
         default: break;
     }
@@ -262,22 +278,22 @@ int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
     return LBM_OK;
 }
 
-// One launch (one iteration, or two with the two-step kernel) of a strip that has neighbours: the edge
+// One launch (one iteration, or two/three with a fused kernel) of a strip that has neighbours: the edge
 // rows first, so that their send can start while the interior rows are still being updated.
 //   compute stream : wait(ev_comm of the previous launch) -> edge rows -> record(ev_edge) -> interior rows
 //   comm stream    : wait(ev_edge) -> ncclSend/ncclRecv group -> record(ev_comm)
-// Edge = the E rows next to a neighbour (E = GR for one iteration, one tile band for two), which contain the GR rows
+// Edge = the E rows next to a neighbour (E = GR for one iteration, one tile band when fused), which contain the GR rows
 // that are sent. Hazards covered by the two events: edge(n) reads the ghost rows recv(n-1) wrote; recv(n) overwrites
 // ghost rows of the buffer edge(n-1) read (ordered through ev_edge(n) on the comm stream); send(n) reads what
 // edge(n) wrote; edge(n+1) overwrites rows send(n-1) read (ordered through ev_comm(n)). Interior rows read no ghost
 // row (E >= GR) and write no edge row.
 template <typename T>
-int advance_with_exchange(lbm_ctx* c, int src, int dst, int t, bool pair) {
+int advance_with_exchange(lbm_ctx* c, int src, int dst, int t, int depth) {
     KArgs<T> a = make_kargs<T>(c, src, dst, t);
     const bool has_s = c->rank > 0 || c->loopback, has_n = c->rank + 1 < c->nranks || c->loopback;
     auto launch = [&](int lo, int cnt, int reverse) {
         a.y_lo = lo; a.y_cnt = cnt; a.reverse = reverse;
-        if (pair) launch_pair_rows<T>(c, a, c->stream);
+        if (depth > 1) launch_fused_rows<T>(c, a, depth, c->stream);
         else launch_rows<T, MODE_STEP>(c, a, c->stream);
     };
     const int rev = (c->alternate && (c->launches_total & 1)) ? 1 : 0;
@@ -287,7 +303,7 @@ int advance_with_exchange(lbm_ctx* c, int src, int dst, int t, bool pair) {
         return exchange_rccl<T>(c, dst, c->stream);
     }
     if (c->comm_issued) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
-    const int E = pair ? c->pair_ty : GR;
+    const int E = depth > 1 ? c->pair_ty : GR;
     int e0 = has_s ? E : 0, e1 = has_n ? E : 0;
     if (e0 + e1 >= c->nyl) { e0 = c->nyl; e1 = 0; }          // short strip: everything is edge
     if (e0 > 0) launch(0, e0, 0);
@@ -308,30 +324,36 @@ int advance_with_exchange(lbm_ctx* c, int src, int dst, int t, bool pair) {
 
 // One launch without neighbours.
 template <typename T>
-int advance_local(lbm_ctx* c, int src, int dst, int t, bool pair) {
-    return launch_step<T>(c, src, dst, t, pair ? 100 : MODE_STEP, c->stream);
+int advance_local(lbm_ctx* c, int src, int dst, int t, int depth) {
+    return launch_step<T>(c, src, dst, t, depth > 1 ? 100 + depth : MODE_STEP, c->stream);
 }
 
-// Advance by up to `remaining` iterations with ONE launch; returns the number of iterations taken (1 or 2) or <0.
-// Two are fused only when the plan allows it, when iteration t+1 is not a force-output iteration (its post-collision
-// state would never exist in memory) and when at least one more iteration follows inside this call, so that the last
-// launch of every lbm_step call is a single iteration and buf[cur^1] holds the previous iteration's populations
-// (macro snapshot / f_current accessors).
+// Advance by up to `remaining` iterations with ONE launch; returns the number of iterations taken (1..3) or <0.
+// d iterations are fused only when the plan allows it, when none of the iterations t+1 .. t+d-1 is a force-output
+// iteration (their post-collision states never exist in memory) and when at least one more iteration follows inside
+// this call, so that the last launch of every lbm_step call is a single iteration and buf[cur^1] holds the previous
+// iteration's populations (macro snapshot / f_current accessors).
 template <typename T>
 int advance(lbm_ctx* c, int remaining, int of, bool exchange) {
     const int t = c->steps_done;
-    const bool pair = c->pair && pair_possible(c) && remaining >= (c->trailing_pair ? 2 : 3) &&
-                      !(of > 0 && (t + 1) % of == 0) &&
-                      (!exchange || c->nyl >= 2 * GR);
+    int depth = 1;
+    if (c->fuse > 1 && pair_possible(c) && (!exchange || c->nyl >= 2 * GR)) {
+        for (int d = std::min(c->fuse, 3); d >= 2 && depth == 1; --d) {
+            if (remaining < d + (c->trailing_pair ? 0 : 1)) continue;
+            bool ok = true;
+            for (int j = 1; j < d; ++j) ok = ok && !(of > 0 && (t + j) % of == 0);
+            if (ok) depth = d;
+        }
+    }
     const int src = c->cur, dst = c->cur ^ 1;
-    int rc = exchange ? advance_with_exchange<T>(c, src, dst, t, pair) : advance_local<T>(c, src, dst, t, pair);
+    int rc = exchange ? advance_with_exchange<T>(c, src, dst, t, depth) : advance_local<T>(c, src, dst, t, depth);
     if (rc) return rc;
     c->cur = dst;
-    c->steps_done = t + (pair ? 2 : 1);
+    c->steps_done = t + depth;
     c->launches_total++;
-    c->last_was_pair = pair;
+    c->last_was_pair = depth > 1;
     c->restored = false;
-    return pair ? 2 : 1;
+    return depth;
 }
 
 // Make everything issued so far (both streams) visible to work queued on the compute stream afterwards.
@@ -380,11 +402,11 @@ inline int alloc_buffers(lbm_ctx* c) {
 // 4096x1024 fp64 depending on the allocation). All candidates compute bit-identical results, so lbm_initialise
 // times each one on the real buffers (8 warm-up + 24 timed launches, a few ms) and keeps the fastest together
 // with the very allocation it was measured on.
-struct Plan { int layout, variant, nt, alternate, pair, ty, xcd; const char* name; };
+struct Plan { int layout, variant, nt, alternate, fuse, ty, xcd; const char* name; };
 
 inline void apply_plan(lbm_ctx* c, const Plan& pl) {
     configure_layout(c, pl.layout);
-    c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate; c->pair = pl.pair; c->xcd = pl.xcd;
+    c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate; c->fuse = pl.fuse > 0 ? pl.fuse : 1; c->xcd = pl.xcd;
     if (pl.ty) c->pair_ty = pl.ty;
 }
 
@@ -394,7 +416,7 @@ int time_plan(lbm_ctx* c, float* ms_out) {
     if (rc) return rc;
     auto run = [&](int n) -> int {
         for (int k = 0; k < n;) {
-            const int took = advance<T>(c, n - k + 2, 0, false);   // +2: never end on the "last is single" rule
+            const int took = advance<T>(c, n - k + 3, 0, false);   // +3: never end on the "last is single" rule
             if (took < 0) return took;
             k += took;
         }
@@ -416,7 +438,7 @@ int time_plan(lbm_ctx* c, float* ms_out) {
 template <typename T>
 int choose_plan(lbm_ctx* c) {
     const bool strips = c->comm && c->nranks > 1;
-    const Plan fixed = {(strips || c->loopback) ? 1 : c->layout, c->variant, c->use_nt, c->alternate, c->pair, c->pair_ty, c->xcd,
+    const Plan fixed = {(strips || c->loopback) ? 1 : c->layout, c->variant, c->use_nt, c->alternate, c->fuse, c->pair_ty, c->xcd,
                         "fixed by options"};
     std::vector<Plan> cand;
     const bool vec_ok = (c->nx % vec_width<T>() == 0), p2 = pair_possible(c);
@@ -428,21 +450,23 @@ int choose_plan(lbm_ctx* c) {
     const bool can_tune = c->tune && (size_t)c->nx * c->nyl >= (1u << 19) && 2 * need + (1u << 28) < free_b;
     if (!c->tune) cand.push_back(fixed);
     else if (!can_tune) {
-        if (strips) cand.push_back({1, 1, 0, 1, p2 ? 1 : 0, 8, 1, "row-interleaved (default, not measured)"});
-        else cand.push_back({0, vec_ok ? 0 : 1, 0, 1, p2 ? 1 : 0, 8, 0, "planar (default, not measured)"});
+        if (strips) cand.push_back({1, 1, 1, 0, p2 ? 3 : 1, 12, 1, "row-interleaved (default, not measured)"});
+        else cand.push_back({0, vec_ok ? 0 : 1, 1, 0, p2 ? 3 : 1, 12, 0, "planar (default, not measured)"});
     } else {
         // strips exchange GR rows x 9 sub-rows as one contiguous run: row-interleaved only
-        if (p2) cand.push_back({1, 1, 1, 0, 1, 8, 1, "row-interleaved/2-step 64x8/nt-store/xcd"});
-        if (p2) cand.push_back({1, 1, 1, 0, 1, 12, 1, "row-interleaved/2-step 64x12/nt-store/xcd"});
-        if (p2) cand.push_back({1, 1, 0, 1, 1, 8, 1, "row-interleaved/2-step 64x8/alternate/xcd"});
-        cand.push_back({1, 1, 1, 0, 0, 0, 0, "row-interleaved/site/nt-store"});
-        cand.push_back({1, 1, 0, 1, 0, 0, 0, "row-interleaved/site/alternate"});
+        if (p2) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
+        if (p2) cand.push_back({1, 1, 1, 0, 3, 8, 1, "row-interleaved/3-step 64x8/nt-store/xcd"});
+        if (p2) cand.push_back({1, 1, 1, 0, 2, 12, 1, "row-interleaved/2-step 64x12/nt-store/xcd"});
+        if (p2) cand.push_back({1, 1, 1, 0, 2, 8, 1, "row-interleaved/2-step 64x8/nt-store/xcd"});
+        cand.push_back({1, 1, 1, 0, 1, 0, 0, "row-interleaved/site/nt-store"});
+        cand.push_back({1, 1, 0, 1, 1, 0, 0, "row-interleaved/site/alternate"});
         if (!strips) {
-            if (p2) cand.push_back({0, 0, 1, 0, 1, 8, 0, "planar/2-step 64x8/nt-store"});
-            if (p2) cand.push_back({0, 0, 1, 0, 1, 12, 0, "planar/2-step 64x12/nt-store"});
-            if (p2) cand.push_back({0, 0, 0, 1, 1, 8, 0, "planar/2-step 64x8/alternate"});
-            if (vec_ok) cand.push_back({0, 0, 0, 1, 0, 0, 0, "planar/vec16B/alternate"});
-            cand.push_back({0, 1, 0, 1, 0, 0, 0, "planar/site/alternate"});
+            if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 1, "planar/3-step 64x12/nt-store/xcd"});
+            if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 0, "planar/3-step 64x12/nt-store"});
+            if (p2) cand.push_back({0, 0, 1, 0, 2, 12, 0, "planar/2-step 64x12/nt-store"});
+            if (p2) cand.push_back({0, 0, 0, 1, 3, 12, 0, "planar/3-step 64x12/alternate"});
+            if (vec_ok) cand.push_back({0, 0, 0, 1, 1, 0, 0, "planar/vec16B/alternate"});
+            cand.push_back({0, 1, 0, 1, 1, 0, 0, "planar/site/alternate"});
         }
     }
     void* best_buf[2] = {nullptr, nullptr};
@@ -960,14 +984,15 @@ int lbm_load_state(lbm_ctx* c, const char* path) {
 int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     if (!c || !key) return fail(LBM_ERR_ARG, "null argument");
     const std::string k(key);
-    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune" || k == "pair" || k == "pair_ty" || k == "loopback"))
+    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune" || k == "pair" || k == "fuse" || k == "pair_ty" || k == "loopback"))
         return fail(LBM_ERR_ARG, "option %s must be set before lbm_initialise", key);
     if (k == "variant") c->variant = (int)value;
     else if (k == "timing") c->timing = (int)value;
     else if (k == "alternate") c->alternate = (int)value;
     else if (k == "layout") c->layout = (int)value ? 1 : 0;
     else if (k == "nt") c->use_nt = (int)value ? 1 : 0;
-    else if (k == "pair") c->pair = (int)value ? 1 : 0;
+    else if (k == "fuse") { if (value < 1 || value > 3) return fail(LBM_ERR_ARG, "fuse must be 1, 2 or 3"); c->fuse = (int)value; }
+    else if (k == "pair") c->fuse = (int)value ? 2 : 1;
     else if (k == "trailing_pair") c->trailing_pair = (int)value ? 1 : 0;
     else if (k == "xcd") c->xcd = (int)value ? 1 : 0;
     else if (k == "loopback") c->loopback = (int)value ? 1 : 0;
@@ -1009,7 +1034,7 @@ const char* lbm_kernel_name(const lbm_ctx* c) {
     static thread_local char name[96];
     const char* t = c->p.precision == LBM_PRECISION_F32 ? "float" : "double";
     const char* nt = c->use_nt ? "true" : "false";
-    if (c->pair && pair_possible(c)) snprintf(name, sizeof(name), "k_step2_tile<%s,%d,%d,%s,%s>", t, c->pair_ty, c->pair_ty == 12 ? 768 : 512, nt, c->xcd ? "true" : "false");
+    if (c->fuse > 1 && pair_possible(c)) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%s,%s>", c->fuse, t, c->pair_ty, c->pair_ty == 12 ? 768 : 512, nt, c->xcd ? "true" : "false");
     else if (use_vec(c)) snprintf(name, sizeof(name), "k_step_vec<%s,%d,0,%s>", t, (int)(16 / c->esize), nt);
     else snprintf(name, sizeof(name), "k_step_site<%s,0,%s>", t, nt);
     return name;

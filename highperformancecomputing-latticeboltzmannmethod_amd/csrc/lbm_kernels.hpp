@@ -5,8 +5,8 @@
 //
 //     plane i, local row gy in [0, ny_loc+2*GR), column col:   base[i*plane + gy*pitch + col]
 //     interior cell (x, y)  <->  gy = y+GR, col = xoff + x      (xoff*sizeof(T) is a multiple of 128 B)
-// GR = 2 ghost rows on each side (the two-step kernel of a strip needs its neighbours' two edge rows); one ghost
-// column on each side.
+// GR = 3 ghost rows on each side (a launch that fuses up to three iterations recomputes up to two of a neighbouring
+// strip's rows and needs its three edge rows); one ghost column on each side.
 // The two strides describe either of two layouts chosen by the host (lbm_hip.hip, "plan"):
 //     PLANAR          plane = rows*pitch0 (+pad), pitch = pitch0            nine separate planes
 //     ROW-INTERLEAVED plane = pitch0,             pitch = 9*pitch0          [gy][i][col]: the nine sub-rows of a
@@ -32,7 +32,7 @@
 namespace lbmk {
 
 constexpr int Q = 9;
-constexpr int GR = 2;   // ghost rows below and above the strip
+constexpr int GR = 3;   // ghost rows below and above the strip (= the deepest fusion: three iterations per launch)
 // LBMConfig.h:13-34 — direction numbering is observable through f_current(x,y,i), keep it.
 __host__ __device__ constexpr int cx(int i) { constexpr int v[Q] = {0, 1, 0, -1, 0, 1, -1, -1, 1}; return v[i]; }
 __host__ __device__ constexpr int cy(int i) { constexpr int v[Q] = {0, 0, 1, 0, -1, 1, 1, -1, -1}; return v[i]; }
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
 // P_{t+2}. P_{t+1} never touches HBM: traffic per lattice update drops from 144 B to ~(1 + (TX+2)(TY+2)/(TX TY))*36 B
 // (82 B at 64x8, less when the tile halo is still in L2 / Infinity Cache). Same arithmetic per cell => results
 // bit-identical to two k_step_site launches (tests). Requires nx % 64 == 0; rows of neighbouring strips must be
-// present two deep (GR = 2). LDS: 9*(TY+2)*(TX+4)*sizeof(T) (47.9 KB at TY=8, fp64: three blocks per CU).
+// present (at least) two deep. LDS: 9*(TY+2)*(TX+4)*sizeof(T) (47.9 KB at TY=8, fp64: three blocks per CU).
 template <typename T> struct K2Extra { T feq_in[Q]; };
 
 template <typename T, int TY, int NTH, bool NT, bool XCD = false>
@@ -329,6 +329,127 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
         }
     }
     if (bad) atomicMin(a.unstable_t, a.t + 1);
+}
+
+// Three iterations per launch. Same idea one level deeper; the LDS image is reused in place:
+//   phase 1  region 1 = tile + 2 rings: P_{t+1} from global P_t into LDS (9*(TY+4)*(TX+4)*sizeof(T): 78 KB at 64x12
+//            fp64, two blocks per CU);
+//   phase 2  region 2 = tile + 1 ring: every thread first pulls its (<= 2) cells' nine values of P_{t+1} from LDS into
+//            registers, barrier, then computes P_{t+2} and writes it IN PLACE (no second LDS image);
+//   phase 3  the tile: pull P_{t+2} from LDS, BCs, collide, store P_{t+3}.
+// HBM traffic per update ~ (1 + (TX+4)(TY+4)/(TX TY)) * 24 B (58 B at 64x12); redundant collisions 1.21x. Bit-identical to
+// three single launches (tests). Rows of neighbouring strips must be present three deep (GR = 3).
+template <typename T, int TY, int NTH, bool NT, bool XCD>
+__global__ void __launch_bounds__(NTH) k_step3_tile(const KArgs<T> a, const K2Extra<T> e) {
+    constexpr int TX = 64, R1W = TX + 4, R1H = TY + 4, R2W = TX + 2, R2H = TY + 2, LP = R1W;
+    static_assert(R2W * R2H <= 2 * NTH, "two region-2 cells per thread at most");
+    __shared__ T lds[Q][R1H][LP];
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (XCD) {
+        const int nb = gridDim.x * gridDim.y;
+        int b = by * gridDim.x + bx;
+        if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;
+        by = b / gridDim.x; bx = b - by * gridDim.x;
+    }
+    if (a.reverse) by = (int)gridDim.y - 1 - by;
+    const int X0 = bx * TX, Y0 = a.y_lo + by * TY;
+    const int y_end = a.y_lo + a.y_cnt;
+    auto outside_value = [&](bool row_in, bool col_in, int i) -> T { return (row_in && !col_in) ? T(0) : e.feq_in[i]; };
+    bool bad = false;
+    for (int r = threadIdx.x; r < R1W * R1H; r += NTH) {                 // phase 1: iteration t
+        const int ry = r / R1W, rx = r - ry * R1W;
+        const int x = X0 + rx - 2, y = Y0 + ry - 2;
+        const int yg = a.y_start + y;
+        const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+        T f[Q];
+        if (!(row_in && col_in) || y > y_end + 1) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
+        } else {
+            const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
+            const bool solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+            T rho_bc, u_out;
+            if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+            bad |= any_unstable(f);
+            if (solid) {
+#pragma unroll
+                for (int i = 0; i < Q; ++i) f[i] = wgt<T>(i);
+            } else bgk_collide(f, a.tau_inv);
+        }
+#pragma unroll
+        for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
+    }
+    if (bad) atomicMin(a.unstable_t, a.t);
+    __syncthreads();
+    // phase 2: iteration t+1 on region 2, in place
+    T g[2][Q];
+    int cell[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = threadIdx.x + k * NTH;
+        cell[k] = (r < R2W * R2H) ? r : -1;
+        if (cell[k] >= 0) {
+            const int ry = r / R2W + 1, rx = r - (r / R2W) * R2W + 1;    // LDS coordinates of the cell
+#pragma unroll
+            for (int i = 0; i < Q; ++i) g[k][i] = lds[i][ry - cy(i)][rx - cx(i)];
+        }
+    }
+    __syncthreads();
+    bad = false;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (cell[k] < 0) continue;
+        const int r = cell[k];
+        const int ry = r / R2W + 1, rx = r - (r / R2W) * R2W + 1;
+        const int x = X0 + rx - 2, y = Y0 + ry - 2;
+        const int yg = a.y_start + y;
+        const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+        T f[Q];
+        if (!(row_in && col_in)) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = g[k][i];
+            const bool solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+            T rho_bc, u_out;
+            if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+            if (y <= y_end) bad |= any_unstable(f);
+            if (solid) {
+#pragma unroll
+                for (int i = 0; i < Q; ++i) f[i] = wgt<T>(i);
+            } else bgk_collide(f, a.tau_inv);
+        }
+#pragma unroll
+        for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
+    }
+    if (bad) atomicMin(a.unstable_t, a.t + 1);
+    __syncthreads();
+    bad = false;
+    for (int o = threadIdx.x; o < TX * TY; o += NTH) {                    // phase 3: iteration t+2 on the tile
+        const int ly = o / TX, lx = o - ly * TX;
+        const int x = X0 + lx, y = Y0 + ly;
+        if (y >= y_end) continue;
+        const int yg = a.y_start + y;
+        T f[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) f[i] = lds[i][ly + 2 - cy(i)][lx + 2 - cx(i)];
+        const bool solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+        T rho_bc, u_out;
+        if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+        bad |= any_unstable(f);
+        if (solid) continue;
+        bgk_collide(f, a.tau_inv);
+        const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            T* p = a.dst + (long)i * a.plane + c;
+            if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
+        }
+    }
+    if (bad) atomicMin(a.unstable_t, a.t + 2);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -99,7 +99,7 @@ int  lbm_get_populations(lbm_ctx* c, int which, double* aos);
 int  lbm_get_solid(lbm_ctx* c, unsigned char* mask);
 
 /* ---- strip halo exchange (replaces Grid::exchange_ghost_cells, LBMGrid.h:249-283) ----
- * Device path: RCCL send/recv of the two edge rows per face (one contiguous run in the row-interleaved layout) after
+ * Device path: RCCL send/recv of the LBM_HALO_ROWS edge rows per face (one contiguous run in the row-interleaved layout) after
  * every launch, on a side stream, overlapped with the interior update. `unique_id` is the 128-byte ncclUniqueId produced by
  * lbm_comm_unique_id on rank 0 and distributed by the launcher. Ranks are ordered bottom (0) to top. */
 int  lbm_comm_unique_id(void* id128);
@@ -108,13 +108,14 @@ int  lbm_comm_init(lbm_ctx* c, int rank, int nranks, const void* id128);
  * LBMIO.h:167-168, LBMGrid.h:315,342). In place, host values, n doubles. op: 0 sum, 1 max, 2 min. */
 int  lbm_comm_allreduce(lbm_ctx* c, double* vals, int n, int op);
 /* Host-staged path (the buffers the reference hands to MPI_Isend/Irecv, LBMGrid.h:255-276). Each face buffer is
- * [LBM_HALO_ROWS][9][nx] doubles: the LBM_HALO_ROWS (= 2) interior rows next to that face, bottom row first, all nine
- * populations (two rows because lbm_step may fuse two iterations per launch and recomputes the neighbour's edge row).
+ * [LBM_HALO_ROWS][9][nx] doubles: the LBM_HALO_ROWS (= 3) interior rows next to that face, bottom row first, all nine
+ * populations (three rows because a launch may fuse up to three iterations and recomputes the neighbour's edge rows).
  * export: south_out = my bottom rows, north_out = my top rows; import: south_in -> my south ghost rows (= the south
  * neighbour's north_out), north_in -> my north ghost rows. NULL = that side is a physical wall. The caller exchanges
- * after lbm_initialise and after EVERY lbm_step call, and calls lbm_step with nsteps <= 2 (one launch). Used by
+ * after lbm_initialise and after EVERY lbm_step call, and calls lbm_step so that it issues ONE launch (nsteps = 1, or
+ * nsteps = 2 / 3 with the options "fuse" >= nsteps and "trailing_pair" 1 and no force-output iteration inside). Used by
  * MPI-hosted callers and by the 2-rank tests. */
-#define LBM_HALO_ROWS 2
+#define LBM_HALO_ROWS 3
 int  lbm_halo_export(lbm_ctx* c, double* south_out, double* north_out);
 int  lbm_halo_import(lbm_ctx* c, const double* south_in, const double* north_in);
 
@@ -128,8 +129,9 @@ int  lbm_load_state(lbm_ctx* c, const char* path);
  *   "tune" 1|0    time the candidate plans at lbm_initialise and keep the fastest (default 1); with 0 the plan is
  *                 "layout" 0 planar|1 row-interleaved, "variant" 0 16-B-per-lane kernel|1 one site per thread,
  *                 "nt" non-temporal stores, "alternate" alternate the row walk direction per launch,
- *                 "pair" 1 fuse two iterations per launch through LDS (k_step2_tile; needs nx % 64 == 0),
- *                 "pair_ty" 8|12 its tile height
+ *                 "fuse" 1|2|3 iterations fused per launch through LDS (k_step2_tile / k_step3_tile; needs
+ *                 nx % 64 == 0; "pair" 1 == "fuse" 2), "pair_ty" 8|12 tile height, "xcd" XCD-aware tile walk,
+ *                 "trailing_pair" 1 lets an lbm_step call end on a fused launch (snapshots then need one more step)
  *   "timing" 1    record HIP events around each lbm_step call (lbm_last_step_kernel_ms). */
 int  lbm_set_option(lbm_ctx* c, const char* key, long value);
 /* Average device time per step-kernel launch (ms) measured with HIP events on the context's stream around

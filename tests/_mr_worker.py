@@ -50,7 +50,7 @@ def main():
     else:
         pairs = backend.endswith("-pair")
         backend = backend.replace("-pair", "")
-        opts = dict(tune=0, layout=1, variant=1, nt=1, pair=1, trailing_pair=1) if pairs else None
+        opts = dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=8, xcd=1, trailing_pair=1) if pairs else None
         ctx = lbm.Context(nx, ny, y_start=y0, local_ny=nloc, device=0, options=opts, **kw)
         halo = lbm.GlooHalo(rank, world, (ctx.HALO_ROWS, 9, nx))
         if backend == "hip-rccl":
@@ -69,8 +69,14 @@ def main():
             halo.exchange(ctx.halo_export, ctx.halo_import)
             done = 0
             while done < steps:
-                # with pairs: two iterations per launch (one exchange per launch), the last one single
-                n = 2 if (pairs and steps - done >= 3 and (done + 1) % of != 0) else 1
+                # fused launches: up to three iterations per launch (one exchange per launch), the last one single;
+                # same rule as lbm_hip.hip `advance`, so that every lbm_step call is exactly one launch
+                n = 1
+                if pairs:
+                    for d in (3, 2):
+                        if steps - done >= d + 1 and all((done + j) % of != 0 for j in range(1, d)):
+                            n = d
+                            break
                 ctx.step(n, of)
                 done += n
                 halo.exchange(ctx.halo_export, ctx.halo_import)

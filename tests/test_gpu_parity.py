@@ -36,7 +36,20 @@ PLANS = {
     # two iterations fused per launch through LDS (k_step2_tile; falls back to one per launch when nx % 64 != 0)
     "planar-pair8-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, pair=1, pair_ty=8),
     "rowil-pair12-alt": dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair=1, pair_ty=12, xcd=1),
+    # three iterations fused per launch (k_step3_tile)
+    "planar-fuse3-8": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=3, pair_ty=8),
+    "rowil-fuse3-12-nt-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1),
 }
+
+
+def fused_depth(plan_opts, steps_left, done, of):
+    """The depth the library picks for the next launch (lbm_hip.hip: advance) when it is asked for exactly that many
+    iterations with trailing_pair=1 — the host-staged strip drivers below must issue ONE launch per lbm_step call."""
+    maxd = (plan_opts or {}).get("fuse", 2 if (plan_opts or {}).get("pair") else 1)
+    for d in (3, 2):
+        if d <= maxd and steps_left >= d + 1 and all(of <= 0 or (done + j) % of != 0 for j in range(1, d)):
+            return d
+    return 1
 
 
 def run_gpu(lbm, g, plan=None, **extra):
@@ -133,7 +146,8 @@ def test_golden_unstable_timestep(lbm, name, plan):
     (128, 70, 333, dict(inlet_velocity=0.09, cylinder_radius=0.1)),  # nx % 64 == 0, ny not a multiple of the tile
     (64, 9, 45, dict(cylinder_x=-1.0, cylinder_radius=0.0)),          # a single tile column, partial second tile row
 ])
-@pytest.mark.parametrize("plan", ["auto", "planar-site", "rowil-vec-nt-alt", "planar-pair8-nt", "rowil-pair12-alt"])
+@pytest.mark.parametrize("plan", ["auto", "planar-site", "rowil-vec-nt-alt", "planar-pair8-nt", "rowil-pair12-alt",
+                                  "planar-fuse3-8", "rowil-fuse3-12-nt-xcd"])
 def test_against_oracle(lbm, nx, ny, steps, kw, plan):
     from oracle.oracle import Oracle, make_params
     of = max(1, steps // 5)
@@ -195,7 +209,8 @@ def _run_strips(lbm, nx, ny, bounds, steps, of, precision="f64", plans=None, pai
     exchange()                            # P_0 edge rows
     done = 0
     while done < steps:
-        n = 2 if (pairs and steps - done >= 3 and (of <= 0 or (done + 1) % of != 0)) else 1
+        # all strips must take the same number of iterations per launch: the smallest depth any of them would pick
+        n = min(fused_depth(PLANS[pl] if pl else None, steps - done, done, of) for pl in plans) if pairs else 1
         for c in ctxs:
             c.step(n, of)
         done += n
@@ -231,8 +246,10 @@ def test_strips_match_single_domain_bitwise(lbm):
         c.close()
 
 
-def test_strips_with_fused_pairs_match_single_domain_bitwise(lbm):
-    """Strips whose launches fuse two iterations: the two-deep halo (LBM_HALO_ROWS) makes the recomputed edge rows
+@pytest.mark.parametrize("strip_plans", [["planar-pair8-nt", "rowil-pair12-alt", "rowil-pair12-alt"],
+                                         ["planar-fuse3-8", "rowil-fuse3-12-nt-xcd", "rowil-fuse3-12-nt-xcd"]])
+def test_strips_with_fused_launches_match_single_domain_bitwise(lbm, strip_plans):
+    """Strips whose launches fuse two / three iterations: the LBM_HALO_ROWS-deep halo makes the recomputed edge rows
     identical to the neighbour's own; result == the one-domain run, bit for bit."""
     nx, ny, steps, of = 192, 60, 121, 40
     kw = dict(inlet_velocity=0.06, cylinder_radius=0.12)
@@ -243,7 +260,7 @@ def test_strips_with_fused_pairs_match_single_domain_bitwise(lbm):
         w_fn = whole.populations("f_next")
         w_log = whole.drain_force_log()
     ctxs, _ = _run_strips(lbm, nx, ny, [(0, 25), (25, 8), (33, 27)], steps, of, pairs=True,
-                          plans=["planar-pair8-nt", "rowil-pair12-alt", "rowil-pair12-alt"], **kw)
+                          plans=strip_plans, **kw)
     parts = [c.macros() for c in ctxs]
     for j in range(3):
         assert np.array_equal(np.concatenate([p[j] for p in parts], axis=0), w[j])
@@ -255,7 +272,7 @@ def test_strips_with_fused_pairs_match_single_domain_bitwise(lbm):
         c.close()
 
 
-@pytest.mark.parametrize("pair", [0, 1])
+@pytest.mark.parametrize("pair", [1, 2, 3])
 def test_overlap_choreography_with_loopback_halo(lbm, pair):
     """The strip step as it runs under RCCL — edge rows first, exchange on the side stream, interior rows overlapped,
     two events — with the test-only loopback transport (the strip is its own neighbour: device copies instead of
@@ -264,8 +281,8 @@ def test_overlap_choreography_with_loopback_halo(lbm, pair):
     kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
     out = []
     for overlap in (0, 1):
-        with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, pair=pair, xcd=1, loopback=1,
-                                              overlap=overlap), **kw) as ctx:
+        with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, fuse=pair, pair_ty=12, xcd=1,
+                                              loopback=1, overlap=overlap), **kw) as ctx:
             ctx.initialise()
             ctx.step(steps, 50)
             ctx.sync()
@@ -316,7 +333,7 @@ def test_c4_grid_8192x2048_single_gpu(lbm):
         w = ctx.macros()
     o.close()
     ctxs, _ = _run_strips(lbm, nx, ny, lbm.partition_rows(ny, 8), steps, 0, pairs=True,
-                          plans=["rowil-pair12-alt"] * 8, **kw)
+                          plans=["rowil-fuse3-12-nt-xcd"] * 8, **kw)
     parts = [c.macros() for c in ctxs]
     for j in range(3):
         assert np.array_equal(np.concatenate([p[j] for p in parts], axis=0), w[j])
@@ -325,9 +342,9 @@ def test_c4_grid_8192x2048_single_gpu(lbm):
 
 
 def test_snapshot_refused_after_trailing_pair(lbm):
-    with lbm.Context(128, 32, options=dict(tune=0, pair=1, trailing_pair=1)) as ctx:
+    with lbm.Context(128, 32, options=dict(tune=0, fuse=3, trailing_pair=1)) as ctx:
         ctx.initialise()
-        ctx.step(2, 0)
+        ctx.step(3, 0)
         with pytest.raises(lbm.LbmError, match="snapshot unavailable"):
             ctx.macros()
         ctx.step(1, 0)
@@ -341,7 +358,7 @@ def test_fp32_variant_tracks_fp64(lbm):
     kw = dict(inlet_velocity=0.05)
     out = {}
     for prec, plan in (("f64", None), ("f32", None), ("f32b", "rowil-vec-nt-alt"), ("f32c", "planar-site"),
-                       ("f32d", "planar-pair8-nt")):
+                       ("f32d", "planar-pair8-nt"), ("f32e", "rowil-fuse3-12-nt-xcd")):
         with lbm.Context(nx, ny, precision=prec[:3], options=PLANS[plan] if plan else None, **kw) as ctx:
             ctx.initialise()
             ctx.step(steps, 0)
@@ -349,7 +366,7 @@ def test_fp32_variant_tracks_fp64(lbm):
             out[prec] = ctx.macros()
     er, eu = macro_errors(*out["f32"], *out["f64"])
     assert er < 2e-4 and eu < 2e-4, (er, eu)
-    for other in ("f32b", "f32c", "f32d"):       # every fp32 formulation is the same arithmetic: bit-identical
+    for other in ("f32b", "f32c", "f32d", "f32e"):       # every fp32 formulation is the same arithmetic: bit-identical
         for a, b in zip(out["f32"], out[other]):
             assert np.array_equal(a, b)
 

@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(256) k_site_vec(const KArgs<T> a) {
 }
 
 
+
 static long g_boff = 0;
 static bool g_single = false;
 static bool g_leak = false;
@@ -231,6 +232,11 @@ void suite(int nx, int ny, long pad, int reps, int rounds, bool rowil, int pitch
         vars.push_back({"step2 TY14 896t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 14, 896, true, true>), g2(14), dim3(896), 0, s, a, ex); }, {}});
         vars.push_back({"step2 TY14 448t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 14, 448, true, true>), g2(14), dim3(448), 0, s, a, ex); }, {}});
         vars.push_back({"step2 TY12 384t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 12, 384, true, true>), g2(12), dim3(384), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY12 768t nt", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 12, 768, true, false>), g2(12), dim3(768), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY12 768t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 12, 768, true, true>), g2(12), dim3(768), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY8 512t nt", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 8, 512, true, false>), g2(8), dim3(512), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY8 512t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 8, 512, true, true>), g2(8), dim3(512), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY16 1024t nt", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 16, 1024, true, false>), g2(16), dim3(1024), 0, s, a, ex); }, {}});
         vars.push_back({"step2 TY16 1024t nt", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 16, 1024, true>), g2(16), dim3(1024), 0, s, a, ex); }, {}});
     }
     if (g_check) {   // step2 variants: 6 launches must equal 12 single steps, bit for bit
@@ -239,9 +245,11 @@ void suite(int nx, int ny, long pad, int reps, int rounds, bool rowil, int pitch
         for (int k = 0; k < 12; ++k) { hipLaunchKernelGGL((k_step_site<T, MODE_STEP>), grid1, dim3(256), 0, s, b.args(b.t & 1)); ++b.t; }
         CK(hipMemcpyAsync(ref.data(), b.A, b.total * sizeof(T), hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s));
         for (auto& v : vars) {
-            if (v.name.rfind("step2", 0) != 0) continue;
+            const bool s2 = v.name.rfind("step2", 0) == 0, s3 = v.name.rfind("step3", 0) == 0;
+            if (!s2 && !s3) continue;
             b.init();
-            for (int k = 0; k < 6; ++k) { KArgs<T> a = b.args(k & 1); a.t = 2 * k; v.fn(a); }
+            const int nl = s2 ? 6 : 4, per = s2 ? 2 : 3;      // 12 iterations either way, result lands in A
+            for (int k = 0; k < nl; ++k) { KArgs<T> a = b.args(k & 1); a.t = per * k; v.fn(a); }
             CK(hipMemcpyAsync(got.data(), b.A, b.total * sizeof(T), hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s));
             size_t diff = 0; for (size_t k = 0; k < b.total; ++k) diff += (memcmp(&ref[k], &got[k], sizeof(T)) != 0);
             printf("CHECK %-24s %s (%zu differing elements)\n", v.name.c_str(), diff ? "MISMATCH" : "bit-identical to 12 single steps", diff);
@@ -257,7 +265,7 @@ void suite(int nx, int ny, long pad, int reps, int rounds, bool rowil, int pitch
            sizeof(T) == 8 ? "f64" : "f32", rowil ? "ROW-INTERLEAVED" : "PLANAR", b.pitch, b.plane, pad, pitch_pad, reps, rounds);
     for (auto& v : vars) {
         std::sort(v.ms.begin(), v.ms.end());
-        const double lup = (v.name.rfind("step2", 0) == 0) ? 2.0 : 1.0;
+        const double lup = (v.name.rfind("step2", 0) == 0) ? 2.0 : (v.name.rfind("step3", 0) == 0) ? 3.0 : 1.0;
         for (auto& m : v.ms) m /= lup;   // per lattice update
         const double med = v.ms[v.ms.size() / 2], mn = v.ms[0];
         printf("  %-26s median %8.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)   best %8.2f us %7.1f GB/s\n", v.name.c_str(), med * 1e3,
