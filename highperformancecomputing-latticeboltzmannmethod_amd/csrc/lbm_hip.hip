@@ -337,7 +337,7 @@ template <typename T>
 int advance(lbm_ctx* c, int remaining, int of, bool exchange) {
     const int t = c->steps_done;
     int depth = 1;
-    if (c->fuse > 1 && pair_possible(c) && (!exchange || c->nyl >= 2 * GR)) {
+    if (c->fuse > 1 && pair_possible(c)) {
         for (int d = std::min(c->fuse, 3); d >= 2 && depth == 1; --d) {
             if (remaining < d + (c->trailing_pair ? 0 : 1)) continue;
             bool ok = true;
@@ -453,13 +453,22 @@ int choose_plan(lbm_ctx* c) {
         if (strips) cand.push_back({1, 1, 1, 0, p2 ? 3 : 1, 12, 1, "row-interleaved (default, not measured)"});
         else cand.push_back({0, vec_ok ? 0 : 1, 1, 0, p2 ? 3 : 1, 12, 0, "planar (default, not measured)"});
     } else {
-        // strips exchange GR rows x 9 sub-rows as one contiguous run: row-interleaved only
-        if (p2) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
-        if (p2) cand.push_back({1, 1, 1, 0, 3, 8, 1, "row-interleaved/3-step 64x8/nt-store/xcd"});
-        if (p2) cand.push_back({1, 1, 1, 0, 2, 12, 1, "row-interleaved/2-step 64x12/nt-store/xcd"});
-        if (p2) cand.push_back({1, 1, 1, 0, 2, 8, 1, "row-interleaved/2-step 64x8/nt-store/xcd"});
-        cand.push_back({1, 1, 1, 0, 1, 0, 0, "row-interleaved/site/nt-store"});
-        cand.push_back({1, 1, 0, 1, 1, 0, 0, "row-interleaved/site/alternate"});
+        // Strips exchange GR rows x 9 sub-rows as one contiguous run: row-interleaved only. Every rank must issue the
+        // same sequence of launches (one exchange per launch), so the fusion depth and tile height of a strip run are
+        // fixed by rule (3 iterations, 64x12 tiles); only rank-local choices are measured.
+        if (strips) {
+            const int f = p2 ? 3 : 1;
+            cand.push_back({1, 1, 1, 0, f, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
+            cand.push_back({1, 1, 1, 0, f, 12, 0, "row-interleaved/3-step 64x12/nt-store"});
+            cand.push_back({1, 1, 0, 1, f, 12, 1, "row-interleaved/3-step 64x12/alternate/xcd"});
+        } else {
+            if (p2) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
+            if (p2) cand.push_back({1, 1, 1, 0, 3, 8, 1, "row-interleaved/3-step 64x8/nt-store/xcd"});
+            if (p2) cand.push_back({1, 1, 1, 0, 2, 12, 1, "row-interleaved/2-step 64x12/nt-store/xcd"});
+            if (p2) cand.push_back({1, 1, 1, 0, 2, 8, 1, "row-interleaved/2-step 64x8/nt-store/xcd"});
+            cand.push_back({1, 1, 1, 0, 1, 0, 0, "row-interleaved/site/nt-store"});
+            cand.push_back({1, 1, 0, 1, 1, 0, 0, "row-interleaved/site/alternate"});
+        }
         if (!strips) {
             if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 1, "planar/3-step 64x12/nt-store/xcd"});
             if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 0, "planar/3-step 64x12/nt-store"});
@@ -913,7 +922,7 @@ int lbm_comm_init(lbm_ctx* c, int rank, int nranks, const void* id128) {
     NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
     c->rank = rank;
     c->nranks = nranks;
-    if (nranks > 1 && c->nyl < GR) return fail(LBM_ERR_ARG, "a strip with neighbours needs at least %d rows", GR);
+    if (nranks > 1 && c->nyl < 2 * GR) return fail(LBM_ERR_ARG, "a strip with neighbours needs at least %d rows", 2 * GR);
     return LBM_OK;
 }
 
