@@ -198,4 +198,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:   # one failing rank must not leave the others waiting at a barrier
+        import traceback
+        traceback.print_exc()
+        sys.stderr.write(f"[bench] rank {os.environ.get('RANK', '0')} failed: {e}\n")
+        sys.stderr.flush()
+        os._exit(1)
