@@ -176,7 +176,7 @@ void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream
     K2Extra<T> e;
     for (int i = 0; i < Q; ++i) e.feq_in[i] = (T)c->feq_in[i];
     const int ty = c->pair_ty;
-    dim3 grid(c->nx / 64, (a.y_cnt + ty - 1) / ty);
+    dim3 grid((c->nx + 63) / 64, (a.y_cnt + ty - 1) / ty);
 #define LBM_K2(TY_, NTH_, NT_, X_) hipLaunchKernelGGL((k_step2_tile<T, TY_, NTH_, NT_, X_>), grid, dim3(NTH_), 0, s, a, e)
 #define LBM_K3(TY_, NTH_, NT_, X_) hipLaunchKernelGGL((k_step3_tile<T, TY_, NTH_, NT_, X_>), grid, dim3(NTH_), 0, s, a, e)
     const int sel = (ty == 12 ? 4 : 0) + (c->use_nt ? 2 : 0) + (c->xcd ? 1 : 0);
@@ -206,7 +206,7 @@ void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream
 #undef LBM_K2
 #undef LBM_K3
 }
-inline bool pair_possible(const lbm_ctx* c) { return c->nx % 64 == 0; }
+inline bool pair_possible(const lbm_ctx*) { return true; }   // partial tiles cover any nx
 
 template <typename T>
 int launch_step(lbm_ctx* c, int src, int dst, int t, int mode, hipStream_t s) {
@@ -447,7 +447,7 @@ int choose_plan(lbm_ctx* c) {
     configure_layout(c, 1);
     const size_t need = 2 * buffer_bytes(c);
     // tiny grids are launch/latency bound (nothing to choose); huge ones cannot afford a second live allocation
-    const bool can_tune = c->tune && (size_t)c->nx * c->nyl >= (1u << 19) && 2 * need + (1u << 28) < free_b;
+    const bool can_tune = c->tune && (size_t)c->nx * c->nyl >= (1u << 16) && 2 * need + (1u << 28) < free_b;
     if (!c->tune) cand.push_back(fixed);
     else if (!can_tune) {
         if (strips) cand.push_back({1, 1, 1, 0, p2 ? 3 : 1, 12, 1, "row-interleaved (default, not measured)"});

@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
 // w_i — into LDS; after one barrier phase 2 pulls from LDS, applies the BCs of iteration t+1, collides and stores
 // P_{t+2}. P_{t+1} never touches HBM: traffic per lattice update drops from 144 B to ~(1 + (TX+2)(TY+2)/(TX TY))*36 B
 // (82 B at 64x8, less when the tile halo is still in L2 / Infinity Cache). Same arithmetic per cell => results
-// bit-identical to two k_step_site launches (tests). Requires nx % 64 == 0; rows of neighbouring strips must be
+// bit-identical to two k_step_site launches (tests). Any nx (partial tiles at the right edge); rows of neighbouring strips must be
 // present (at least) two deep. LDS: 9*(TY+2)*(TX+4)*sizeof(T) (47.9 KB at TY=8, fp64: three blocks per CU).
 template <typename T> struct K2Extra { T feq_in[Q]; };
 
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
     for (int o = threadIdx.x; o < TX * TY; o += NTH) {         // phase 2: iteration t+1 on the tile
         const int ly = o / TX, lx = o - ly * TX;
         const int x = X0 + lx, y = Y0 + ly;
-        if (y >= y_end) continue;
+        if (y >= y_end || x >= a.nx) continue;               // partial tiles at the right / top edge
         const int yg = a.y_start + y;
         T f[Q];
 #pragma unroll
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(NTH) k_step3_tile(const KArgs<T> a, const K2Ex
     for (int o = threadIdx.x; o < TX * TY; o += NTH) {                    // phase 3: iteration t+2 on the tile
         const int ly = o / TX, lx = o - ly * TX;
         const int x = X0 + lx, y = Y0 + ly;
-        if (y >= y_end) continue;
+        if (y >= y_end || x >= a.nx) continue;
         const int yg = a.y_start + y;
         T f[Q];
 #pragma unroll

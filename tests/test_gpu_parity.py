@@ -33,7 +33,7 @@ PLANS = {
     "planar-site": dict(tune=0, layout=0, variant=1, nt=0, alternate=0),
     "rowil-site-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0),
     "rowil-vec-nt-alt": dict(tune=0, layout=1, variant=0, nt=1, alternate=1),
-    # two iterations fused per launch through LDS (k_step2_tile; falls back to one per launch when nx % 64 != 0)
+    # two iterations fused per launch through LDS (k_step2_tile; partial tiles cover any nx)
     "planar-pair8-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, pair=1, pair_ty=8),
     "rowil-pair12-alt": dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair=1, pair_ty=12, xcd=1),
     # three iterations fused per launch (k_step3_tile)
