@@ -74,15 +74,15 @@ struct lbm_ctx {
     double feq_in[Q];
     int cyl_x = 0, cyl_y = 0, cyl_r = 0;
     // options
-    int variant = 0;     // 0: k_step_vec when nx % V == 0; 1: k_step_site
+    int variant = 0;     // single-iteration kernel: 0 = k_step_vec when nx % V == 0, 1 = k_step_site
     int alternate = 1;   // walk the rows bottom-up / top-down on alternate steps (Infinity Cache reuse)
     int use_nt = 0;      // non-temporal stores in the step kernel
     int fuse = 1;        // iterations fused per launch where the schedule allows: 1, 2 (k_step2_tile) or 3 (k_step3_tile)
     int pair_ty = 8;     // tile height of the fused kernels (8 or 12)
     int xcd = 0;         // fused kernels: remap blocks so that each XCD walks a contiguous run of tiles
     int loopback = 0;    // TEST ONLY: the strip is its own north and south neighbour (exercises the overlap choreography)
-    int trailing_pair = 0;   // allow an lbm_step call to END on a fused launch (host-staged strips: nsteps == 2)
-    bool last_was_pair = false;
+    int trailing_pair = 0;   // allow an lbm_step call to END on a fused launch (host-staged strips: one launch per call)
+    bool last_was_pair = false;   // the last launch fused several iterations: buf[cur^1] is older than steps_done-1
     bool restored = false;   // state came from lbm_load_state: no previous-iteration buffer until the next step
     int tune = 1;        // lbm_initialise times the candidate plans on this device and keeps the fastest
     char plan_desc[160] = "";
@@ -243,8 +243,8 @@ int launch_forces(lbm_ctx* c, double* out, int t) {
 // ---- halo exchange over RCCL -------------------------------------------------------------------------
 // After a launch has produced the new populations in buf[dst]: my top GR interior rows go to the north neighbour's
 // south ghost rows, my bottom GR interior rows to the south neighbour's north ghost rows, all nine populations
-// (the two-step kernel recomputes the neighbour's edge row, which needs every population; per lattice update this
-// is the reference's 9 values per edge cell, LBMGrid.h:404-406). Strips always use the row-interleaved layout, in
+// (a fused launch recomputes up to two of the neighbour's rows, which needs every population; per lattice update
+// this is the reference's 9 values per edge cell, LBMGrid.h:404-406). Strips always use the row-interleaved layout, in
 // which GR rows x 9 sub-rows are ONE contiguous run of GR*pitch elements: one send + one recv per face, no packing.
 template <typename T>
 int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
