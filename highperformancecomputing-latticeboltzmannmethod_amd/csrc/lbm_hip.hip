@@ -51,7 +51,7 @@ struct lbm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // compute stream (all kernels)
     hipStream_t comm_stream = nullptr;  // halo exchange (RCCL send/recv)
-    hipEvent_t ev_edge = nullptr, ev_comm = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_edge = nullptr, ev_comm = nullptr, ev_main = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     int nx = 0, nyl = 0, xoff = 0;
     int pitch0 = 0;          // elements of one sub-row (ghost columns + 128-B padding included)
     int pitch = 0;           // ROW stride: elements between consecutive rows of one plane
@@ -122,6 +122,8 @@ KArgs<T> make_kargs(const lbm_ctx* c, int src, int dst, int t) {
     a.t = t;
     a.y_lo = 0;
     a.y_cnt = c->nyl;
+    a.y_lo2 = 0;
+    a.y_cnt2 = 0;
     a.reverse = 0;
     return a;
 }
@@ -160,11 +162,11 @@ void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
     constexpr int V = vec_width<T>();
     const bool nt = (MODE == MODE_STEP) && c->use_nt;
     if (use_vec(c)) {
-        dim3 grid((c->nx / V + 255) / 256, a.y_cnt), block(256);
+        dim3 grid((c->nx / V + 255) / 256, a.y_cnt + a.y_cnt2), block(256);
         if (nt) hipLaunchKernelGGL((k_step_vec<T, V, MODE, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_step_vec<T, V, MODE, false>), grid, block, 0, s, a);
     } else {
-        dim3 grid((c->nx + 255) / 256, a.y_cnt), block(256);
+        dim3 grid((c->nx + 255) / 256, a.y_cnt + a.y_cnt2), block(256);
         if (nt) hipLaunchKernelGGL((k_step_site<T, MODE, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_step_site<T, MODE, false>), grid, block, 0, s, a);
     }
@@ -176,7 +178,7 @@ void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream
     K2Extra<T> e;
     for (int i = 0; i < Q; ++i) e.feq_in[i] = (T)c->feq_in[i];
     const int ty = c->pair_ty;
-    dim3 grid((c->nx + 63) / 64, (a.y_cnt + ty - 1) / ty);
+    dim3 grid((c->nx + 63) / 64, (a.y_cnt + ty - 1) / ty + (a.y_cnt2 + ty - 1) / ty);
 #define LBM_K2(TY_, NTH_, NT_, X_) hipLaunchKernelGGL((k_step2_tile<T, TY_, NTH_, NT_, X_>), grid, dim3(NTH_), 0, s, a, e)
 #define LBM_K3(TY_, NTH_, NT_, X_) hipLaunchKernelGGL((k_step3_tile<T, TY_, NTH_, NT_, X_>), grid, dim3(NTH_), 0, s, a, e)
     const int sel = (ty == 12 ? 4 : 0) + (c->use_nt ? 2 : 0) + (c->xcd ? 1 : 0);
@@ -278,45 +280,52 @@ int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
     return LBM_OK;
 }
 
-// One launch (one iteration, or two/three with a fused kernel) of a strip that has neighbours: the edge
-// rows first, so that their send can start while the interior rows are still being updated.
-//   compute stream : wait(ev_comm of the previous launch) -> edge rows -> record(ev_edge) -> interior rows
-//   comm stream    : wait(ev_edge) -> ncclSend/ncclRecv group -> record(ev_comm)
-// Edge = the E rows next to a neighbour (E = GR for one iteration, one tile band when fused), which contain the GR rows
-// that are sent. Hazards covered by the two events: edge(n) reads the ghost rows recv(n-1) wrote; recv(n) overwrites
-// ghost rows of the buffer edge(n-1) read (ordered through ev_edge(n) on the comm stream); send(n) reads what
-// edge(n) wrote; edge(n+1) overwrites rows send(n-1) read (ordered through ev_comm(n)). Interior rows read no ghost
-// row (E >= GR) and write no edge row.
+// One launch group (one iteration, or two/three with a fused kernel) of a strip that has neighbours.
+// The E rows next to each neighbour ("edge bands": E = GR for one iteration, one tile band when fused) contain the GR
+// rows that are sent. They are updated by ONE launch on the side stream, followed there by the RCCL group; the
+// remaining interior rows are updated concurrently on the main stream:
+//   side stream : wait(ev_main: everything queued on the main stream so far) -> edge bands -> record(ev_edge)
+//                 -> ncclSend/ncclRecv group -> record(ev_comm)
+//   main stream : record(ev_main) ... wait(ev_edge of the PREVIOUS group) -> interior rows
+// Hazards: edge(n) and interior(n) both read rows the other kind wrote in group n-1 (ev_main / ev_edge); edge(n) reads
+// the ghost rows recv(n-1) wrote and recv(n) overwrites ghost rows edge(n-1) read, send(n) reads what edge(n) wrote,
+// edge(n+1) overwrites rows send(n-1) read (all ordered by the side stream itself); interior(n) overwrites rows of
+// the buffer edge(n-1) read (ev_edge). Interior rows read no ghost row (E >= GR) and write no edge row. Consumers on
+// the main stream (forces, snapshots) first wait for ev_comm (join_comm).
 template <typename T>
 int advance_with_exchange(lbm_ctx* c, int src, int dst, int t, int depth) {
     KArgs<T> a = make_kargs<T>(c, src, dst, t);
     const bool has_s = c->rank > 0 || c->loopback, has_n = c->rank + 1 < c->nranks || c->loopback;
-    auto launch = [&](int lo, int cnt, int reverse) {
-        a.y_lo = lo; a.y_cnt = cnt; a.reverse = reverse;
-        if (depth > 1) launch_fused_rows<T>(c, a, depth, c->stream);
-        else launch_rows<T, MODE_STEP>(c, a, c->stream);
+    auto launch = [&](hipStream_t s) {
+        if (depth > 1) launch_fused_rows<T>(c, a, depth, s);
+        else launch_rows<T, MODE_STEP>(c, a, s);
     };
     const int rev = (c->alternate && (c->launches_total & 1)) ? 1 : 0;
     if (!c->overlap) {
-        launch(0, c->nyl, rev);
+        a.reverse = rev;
+        launch(c->stream);
         HIPCHK(hipGetLastError());
         return exchange_rccl<T>(c, dst, c->stream);
     }
-    if (c->comm_issued) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     const int E = depth > 1 ? c->pair_ty : GR;
     int e0 = has_s ? E : 0, e1 = has_n ? E : 0;
     if (e0 + e1 >= c->nyl) { e0 = c->nyl; e1 = 0; }          // short strip: everything is edge
-    if (e0 > 0) launch(0, e0, 0);
-    if (e1 > 0) launch(c->nyl - e1, e1, 0);
+    HIPCHK(hipEventRecord(c->ev_main, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_main, 0));
+    if (c->comm_issued) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_edge, 0));   // ev_edge still is the previous group's
+    a.reverse = 0;
+    a.y_lo = 0; a.y_cnt = e0; a.y_lo2 = c->nyl - e1; a.y_cnt2 = e1;
+    if (e0 == 0) { a.y_lo = a.y_lo2; a.y_cnt = e1; a.y_cnt2 = 0; }
+    launch(c->comm_stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev_edge, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_edge, 0));
+    HIPCHK(hipEventRecord(c->ev_edge, c->comm_stream));
     int rc = exchange_rccl<T>(c, dst, c->comm_stream);
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
     c->comm_issued = true;
     if (c->nyl - e0 - e1 > 0) {
-        launch(e0, c->nyl - e0 - e1, rev);
+        a.y_lo = e0; a.y_cnt = c->nyl - e0 - e1; a.y_lo2 = 0; a.y_cnt2 = 0; a.reverse = rev;
+        launch(c->stream);
         HIPCHK(hipGetLastError());
     }
     return LBM_OK;
@@ -533,7 +542,9 @@ int do_steps(lbm_ctx* c, int nsteps, int of) {
         const int t = c->steps_done;
         if (of > 0 && t % of == 0) {
             if (c->log_count >= c->log_cap) return fail(LBM_ERR_ARG, "force log full (%d rows): drain it", c->log_cap);
-            int rc = launch_forces<T>(c, c->d_force_log + 3L * c->log_count, t);
+            int rc = join_comm(c);      // the edge bands of the previous launch live on the side stream
+            if (rc) return rc;
+            rc = launch_forces<T>(c, c->d_force_log + 3L * c->log_count, t);
             if (rc) return rc;
             c->log_count++;
         }
@@ -543,6 +554,8 @@ int do_steps(lbm_ctx* c, int nsteps, int of) {
         ++launches;
     }
     if (c->timing) {
+        int jr = join_comm(c);
+        if (jr) return jr;
         HIPCHK(hipEventRecord(c->ev_t1, c->stream));
         c->timed_launches = launches;
         c->timed_steps = nsteps;
@@ -745,9 +758,14 @@ int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
     } while (0)
     HIPTRY(hipSetDevice(device));
     HIPTRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPTRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    {   // the side stream carries the edge bands + exchange, which sit on the critical path: highest priority
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPTRY(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, hi));
+    }
     HIPTRY(hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
     HIPTRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+    HIPTRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
     HIPTRY(hipEventCreate(&c->ev_t0));
     HIPTRY(hipEventCreate(&c->ev_t1));
     // the population buffers are allocated by lbm_initialise (the plan decides their layout)
@@ -773,7 +791,7 @@ void lbm_destroy(lbm_ctx* c) {
                     c->d_force_now, c->d_force_log, c->d_halo, c->d_red};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
-    hipEvent_t evs[] = {c->ev_edge, c->ev_comm, c->ev_t0, c->ev_t1};
+    hipEvent_t evs[] = {c->ev_edge, c->ev_comm, c->ev_main, c->ev_t0, c->ev_t1};
     for (hipEvent_t e : evs)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -817,6 +835,7 @@ int lbm_steps_done(const lbm_ctx* c) { return c ? c->steps_done : -1; }
 int lbm_first_unstable_step(lbm_ctx* c, int* t_out) {
     if (!c || !t_out) return fail(LBM_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(c->device));
+    { int jr = join_comm(c); if (jr) return jr; }
     int v = INT_MAX;
     HIPCHK(hipMemcpyAsync(&v, c->d_unstable, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -57,8 +57,10 @@ struct KArgs {
     T u_in;            // inlet velocity
     int* unstable_t;   // device word: first unstable iteration (INT_MAX if none)
     int t;             // iteration this launch completes (stability bookkeeping only)
-    int y_lo, y_cnt;   // local rows [y_lo, y_lo + y_cnt) covered by this launch (grid.y == y_cnt)
-    int reverse;       // 1: blockIdx.y walks the rows top-down (alternated per step by the host, see row_of_block)
+    int y_lo, y_cnt;   // local rows [y_lo, y_lo + y_cnt) covered by this launch
+    int y_lo2, y_cnt2; // optional second range [y_lo2, y_lo2 + y_cnt2) of the same launch (both edge bands of a strip
+                       // in one grid); y_cnt2 == 0: none
+    int reverse;       // 1: blockIdx.y walks the rows top-down (alternated per launch by the host, see row_of_block)
 };
 
 // Row handled by blockIdx.y. Blocks are dispatched roughly in index order; walking the rows in the opposite
@@ -66,7 +68,19 @@ struct KArgs {
 // ones most likely still resident in the 256 MiB Infinity Cache (measured +0..8 % at 4096x1024 fp64).
 template <typename T>
 __device__ __forceinline__ int row_of_block(const KArgs<T>& a) {
-    return a.y_lo + (a.reverse ? a.y_cnt - 1 - (int)blockIdx.y : (int)blockIdx.y);
+    const int by = (int)blockIdx.y;            // grid.y == y_cnt + y_cnt2
+    if (by >= a.y_cnt) return a.y_lo2 + (by - a.y_cnt);
+    return a.y_lo + (a.reverse ? a.y_cnt - 1 - by : by);
+}
+
+// Tile band of a fused launch: bands of TY rows over the first range, then over the second (grid.y = both counts).
+// Returns the first row of the band and, through y_end, the end of the range it belongs to.
+template <typename T>
+__device__ __forceinline__ int band_origin(const KArgs<T>& a, int by, int TY, int& y_end) {
+    const int nb1 = (a.y_cnt + TY - 1) / TY;
+    if (by >= nb1) { y_end = a.y_lo2 + a.y_cnt2; return a.y_lo2 + (by - nb1) * TY; }
+    y_end = a.y_lo + a.y_cnt;
+    return a.y_lo + by * TY;
 }
 
 // Grid::setup_geometry, LBMGrid.h:152-173, as a pure function of GLOBAL integer coordinates.
@@ -288,10 +302,10 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
         if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;
         by = b / gridDim.x; bx = b - by * gridDim.x;
     }
-    if (a.reverse) by = (int)gridDim.y - 1 - by;
+    if (a.reverse) by = (int)gridDim.y - 1 - by;               // (the host never combines reverse with a second range)
     const int X0 = bx * TX;
-    const int Y0 = a.y_lo + by * TY;
-    const int y_end = a.y_lo + a.y_cnt;                        // rows >= y_end belong to another launch
+    int y_end;                                                 // rows >= y_end belong to another band / launch
+    const int Y0 = band_origin(a, by, TY, y_end);
     const bool near_cyl = tile_near_cylinder(a, X0, Y0, TX, TY, 1);   // block-uniform: most tiles skip the mask math
     bool bad = false;
     for (int r = threadIdx.x; r < RW * RH; r += NTH) {         // phase 1: iteration t on the region
@@ -371,8 +385,9 @@ __global__ void __launch_bounds__(NTH) k_step3_tile(const KArgs<T> a, const K2Ex
         by = b / gridDim.x; bx = b - by * gridDim.x;
     }
     if (a.reverse) by = (int)gridDim.y - 1 - by;
-    const int X0 = bx * TX, Y0 = a.y_lo + by * TY;
-    const int y_end = a.y_lo + a.y_cnt;
+    const int X0 = bx * TX;
+    int y_end;
+    const int Y0 = band_origin(a, by, TY, y_end);
     const bool near_cyl = tile_near_cylinder(a, X0, Y0, TX, TY, 2);
     auto outside_value = [&](bool row_in, bool col_in, int i) -> T { return (row_in && !col_in) ? T(0) : e.feq_in[i]; };
     bool bad = false;

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""tools/strip_proxy.py — how host-bound is one rank of an N-strip run? Runs a 4096 x (1024/N) strip on one GPU with the
+loopback halo transport (same host-side choreography as the RCCL path: edge launches, events, side stream; device
+copies in place of ncclSend/ncclRecv) and reports us per iteration vs the same strip without any exchange."""
+import importlib
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+lbm = importlib.import_module("highperformancecomputing-latticeboltzmannmethod_amd")
+nx, ny = 4096, 1024
+for n in (1, 2, 4, 8):
+    rows = ny // n
+    line = [f"N={n} rows={rows}:"]
+    for name, opts in (("no-exchange", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1)),
+                       ("loopback overlap", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, loopback=1, overlap=1)),
+                       ("loopback serial", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, loopback=1, overlap=0))):
+        with lbm.Context(nx, rows, inlet_velocity=0.05, options=opts) as c:
+            c.initialise()
+            c.step(300, 0); c.sync()
+            t0 = time.perf_counter(); c.step(3000, 0); c.sync(); dt = time.perf_counter() - t0
+            line.append(f"{name} {dt / 3000 * 1e6:.2f} us/it ({nx * rows * 3000 / dt / 1e6 * n:.0f} MLUPS x{n} ranks)")
+    print("  ".join(line), flush=True)
