@@ -34,9 +34,6 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 BYTES_PER_LUP = {"f64": 144, "f32": 72}   # 9 loads + 9 stores per lattice update
 
 
-from oracle.oracle import host_cores  # cpu_baseline leg only (test infrastructure)
-
-
 def _time_reference(ref, d, nx, ny, u_in, steps, threads):
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="true", OMP_PLACES="cores")
     out = subprocess.run([ref, "--nx", str(nx), "--ny", str(ny), "--steps", str(steps), "--of", "1000000",
@@ -49,7 +46,9 @@ def _time_reference(ref, d, nx, ny, u_in, steps, threads):
 
 
 def cpu_baseline(nx, ny, u_in, budget_s=12.0):
-    """Reported baseline only: the reference's CPU path on this host's cores, bounded sample of the same grid."""
+    """Reported baseline only: the reference's CPU path on this host's cores, bounded sample of the same grid.
+    (The only place bench.py touches oracle/: the checker's thread-count helper and, as a fallback, its CPU port.)"""
+    from oracle.oracle import host_cores
     cores = host_cores()
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     if os.path.exists(ref):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/parity_report.py — prints the observed GPU-vs-oracle / GPU-vs-golden errors (for DESIGN.md §parity)."""
+"""tests/parity_report.py — prints the observed GPU-vs-oracle / GPU-vs-golden errors (for DESIGN.md §parity).
+Test infrastructure (it loads the oracle as the checker); not collected by pytest. Run: python tests/parity_report.py"""
 import importlib
 import os
 import sys
