@@ -19,7 +19,13 @@
 // are refreshed every step by the halo exchange. The step kernel therefore needs no boundary branches for
 // its nine pulls and writes fluid interior cells only.
 //
-// Step kernel K_t (one launch per loop body of Solver::run, LBMSolver.h:49-60):
+// Kernel families (all evaluate the SAME per-cell operation sequence => bit-identical results):
+//   k_step_site / k_step_vec   one iteration per launch, 144 B of HBM traffic per lattice update (fp64)
+//   k_step2_tile / k_step3_tile two / three iterations per launch, intermediate states in LDS: 84 / 60 B per update
+//                               measured (production path: 89-93 GLUPS at 4096x1024 fp64 on one MI355X)
+//   k_init, k_macros, k_forces, k_halo_pack/unpack   set-up and the output cadence
+//
+// Step kernel K_t (one iteration = one loop body of Solver::run, LBMSolver.h:49-60):
 //     pull from P_t        == exchange_ghost_cells + streaming_step        (LBMGrid.h:249, LBMSolver.h:128-145)
 //     wall / inlet / outlet== apply_boundary_conditions, sequential order  (LBMSolver.h:147-236)
 //     stability test       == Grid::check_stability                        (LBMGrid.h:285-317)
