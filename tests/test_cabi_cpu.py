@@ -57,3 +57,19 @@ def test_product_sources_never_touch_the_oracle():
                     if re.search(r"lbm_oracle|oracle\.oracle|liblbm_oracle|lbmo_", txt):
                         bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_argument_errors_are_reported_without_a_device(pkg):
+    """Error behaviour of the boundary (no exceptions across the C-ABI: negative codes + lbm_last_error text)."""
+    import ctypes as C
+    L = pkg.lib()
+    h = C.c_void_p()
+    assert L.lbm_create(None, 0, C.byref(h)) == -1 and b"null" in L.lbm_last_error()
+    p = pkg.Params(0.6, 0.01, 0, 32, 0.2, 0.5, 0.05, 0, 0, 0, 0)           # nx = 0
+    assert L.lbm_create(C.byref(p), 0, C.byref(h)) == -1 and b"bad nx/ny/tau" in L.lbm_last_error()
+    p = pkg.Params(0.6, 0.01, 64, 32, 0.2, 0.5, 0.05, 0, 0, 7, 0)          # unknown precision
+    assert L.lbm_create(C.byref(p), 0, C.byref(h)) == -1 and b"precision" in L.lbm_last_error()
+    assert L.lbm_step(None, 1, 0) == -1
+    assert L.lbm_steps_done(None) == -1
+    assert L.lbm_set_option(None, b"tune", 0) == -1
+    L.lbm_destroy(None)                                                     # destroying nothing is a no-op
