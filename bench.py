@@ -106,7 +106,9 @@ def main():
     lbm = importlib.import_module(PKG)
     if lbm.device_count() < 1:
         sys.exit("no HIP device: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    ndev = lbm.device_count()
+    device = local_rank % ndev          # (a launcher may expose one device per rank)
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -120,7 +122,7 @@ def main():
     u_in = args.re * ((0.6 - 0.5) / 3.0) / (2.0 * 0.05 * ny_total)
 
     ctx = lbm.Context(nx, ny_total, tau=0.6, inlet_velocity=u_in, y_start=rank * local_ny, local_ny=local_ny,
-                      precision=args.precision, device=local_rank)
+                      precision=args.precision, device=device)
     if args.variant is not None:
         ctx.set_option("variant", args.variant)
     if world > 1:
