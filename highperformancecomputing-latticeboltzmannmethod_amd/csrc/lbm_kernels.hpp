@@ -161,7 +161,8 @@ template <typename T>
 __device__ __forceinline__ bool any_unstable(const T (&f)[Q]) {
     bool bad = false;
 #pragma unroll
-    for (int i = 0; i < Q; ++i) bad |= !(fabs((double)f[i]) <= 1e5);   // NaN, Inf, > 1e5, < -1e5 (LBMGrid.h:296-307)
+    for (int i = 0; i < Q; ++i) bad |= !(fabs(f[i]) <= T(1e5));   // NaN, Inf, > 1e5, < -1e5 (LBMGrid.h:296-307); 1e5 is
+                                                                   // exact in fp32 too, so the test is done in T
     return bad;
 }
 
