@@ -81,8 +81,8 @@ def cpu_baseline(nx, ny, u_in, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--nx", type=int, default=4096)
     ap.add_argument("--ny", type=int, default=1024)
     ap.add_argument("--re", type=float, default=200.0)
