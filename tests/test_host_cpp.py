@@ -87,3 +87,35 @@ def test_lbm_solver_checkpoint_restart_continues_bit_exactly():
     ours = open(os.path.join(d, "forces.csv")).read().splitlines()
     ref = bytes(g["forces_csv"]).decode().splitlines()
     same_text("\n".join(ours[1:]), "\n".join(ref[3:]))      # the restarted run records t = 800 and 1200
+
+
+@pytest.mark.gpu
+def test_cpp_surface_accessors_match_reference_values():
+    """LBM::Solver::step per iteration + the LBM::Grid read accessors (rho/ux/uy/f_current/f_next/is_solid/max_velocity,
+    LBMGrid.h:105-150,319) against the values the unmodified reference returns through the same accessors."""
+    from tests.helpers import macro_errors, linf_rel
+    g = load_golden("g1_128x32_s100")
+    nx, ny = 128, 32
+    d = tempfile.mkdtemp(prefix="lbm_host_")
+    exe = os.path.join(ROOT, PKG, "host", "surface_dump")
+    subprocess.run([exe, str(nx), str(ny), "100", "50", "dump.bin"], cwd=d, check=True, timeout=300)
+    raw = open(os.path.join(d, "dump.bin"), "rb").read()
+    hdr = np.frombuffer(raw[:16], dtype=np.int32)
+    assert list(hdr[:3]) == [nx, ny, 100] and hdr[3] == 1
+    off, n, nf = 16, nx * ny, (nx + 2) * (ny + 2) * 9
+
+    def take(k):
+        nonlocal off
+        a = np.frombuffer(raw[off:off + 8 * k], dtype=np.float64)
+        off += 8 * k
+        return a
+    rho, ux, uy = (take(n).reshape(ny, nx) for _ in range(3))
+    fc, fn = (take(nf).reshape(ny + 2, nx + 2, 9) for _ in range(2))
+    solid = np.frombuffer(raw[off:off + n], dtype=np.uint8).reshape(ny, nx)
+    off += n
+    mv = take(1)[0]
+    er, eu = macro_errors(rho, ux, uy, g["rho"], g["ux"], g["uy"])
+    assert er < 1e-10 and eu < 1e-10
+    assert linf_rel(fc, g["f_current"]) < 1e-10 and linf_rel(fn, g["f_next"]) < 1e-10
+    assert np.array_equal(solid, g["solid"]) and abs(mv - float(g["max_velocity"][0])) < 1e-10
+    same_text(open(os.path.join(d, "forces.csv")).read(), str(g["forces_text"]))
