@@ -80,7 +80,8 @@ struct lbm_ctx {
     int fuse = 1;        // iterations fused per launch where the schedule allows: 1, 2 (k_step2_tile) or 3 (k_step3_tile)
     int pair_ty = 8;     // tile height of the fused kernels (8 or 12)
     int xcd = 0;         // fused kernels: remap blocks so that each XCD walks a contiguous run of tiles
-    int loopback = 0;    // TEST ONLY: the strip is its own north and south neighbour (exercises the overlap choreography)
+    int loopback = 0;    // TEST ONLY: the strip is its own north and south neighbour (exercises the overlap choreography):
+                         // 1 = device copies, 2 = RCCL send/recv to self on a one-rank communicator
     int trailing_pair = 0;   // allow an lbm_step call to END on a fused launch (host-staged strips: one launch per call)
     bool last_was_pair = false;   // the last launch fused several iterations: buf[cur^1] is older than steps_done-1
     bool restored = false;   // state came from lbm_load_state: no previous-iteration buffer until the next step
@@ -250,10 +251,22 @@ int launch_forces(lbm_ctx* c, double* out, int t) {
 // which GR rows x 9 sub-rows are ONE contiguous run of GR*pitch elements: one send + one recv per face, no packing.
 template <typename T>
 int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
-    if (c->loopback) {   // test transport: my own edge rows become my ghost rows (device copies on the same stream)
+    if (c->loopback) {   // test transports: my own edge rows become my ghost rows
         T* b = static_cast<T*>(c->buf[dst]);
         if (c->layout != 1) return fail(LBM_ERR_COMM, "loopback requires the row-interleaved layout");
-        const size_t bytes = (size_t)GR * c->pitch * sizeof(T);
+        if (c->loopback == 2) {   // ... through RCCL itself: a one-rank communicator sending to / receiving from rank 0
+            if (!c->comm) return fail(LBM_ERR_COMM, "loopback=2 needs lbm_comm_init(c, 0, 1, id)");
+            const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+            const size_t cnt = (size_t)GR * c->pitch;
+            NCCLCHK(ncclGroupStart());        // self send/recv pairs match in posting order
+            NCCLCHK(ncclSend(b + (long)c->nyl * c->pitch, cnt, dt, 0, c->comm, s));          // top rows ...
+            NCCLCHK(ncclRecv(b, cnt, dt, 0, c->comm, s));                                    // ... -> south ghost rows
+            NCCLCHK(ncclSend(b + (long)GR * c->pitch, cnt, dt, 0, c->comm, s));              // bottom rows ...
+            NCCLCHK(ncclRecv(b + (long)(c->nyl + GR) * c->pitch, cnt, dt, 0, c->comm, s));   // ... -> north ghost rows
+            NCCLCHK(ncclGroupEnd());
+            return LBM_OK;
+        }
+        const size_t bytes = (size_t)GR * c->pitch * sizeof(T);   // ... or plain device copies on the same stream
         HIPCHK(hipMemcpyAsync(b, b + (long)c->nyl * c->pitch, bytes, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(b + (long)(c->nyl + GR) * c->pitch, b + (long)GR * c->pitch, bytes, hipMemcpyDeviceToDevice, s));
         return LBM_OK;
@@ -763,9 +776,9 @@ int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         HIPTRY(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, hi));
     }
-    HIPTRY(hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
-    HIPTRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
-    HIPTRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+    HIPTRY(hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming | hipEventDisableSystemFence));   // device-side ordering only
+    HIPTRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming | hipEventDisableSystemFence));   // device-side ordering only
+    HIPTRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming | hipEventDisableSystemFence));   // device-side ordering only
     HIPTRY(hipEventCreate(&c->ev_t0));
     HIPTRY(hipEventCreate(&c->ev_t1));
     // the population buffers are allocated by lbm_initialise (the plan decides their layout)
@@ -1023,7 +1036,7 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "pair") c->fuse = (int)value ? 2 : 1;
     else if (k == "trailing_pair") c->trailing_pair = (int)value ? 1 : 0;
     else if (k == "xcd") c->xcd = (int)value ? 1 : 0;
-    else if (k == "loopback") c->loopback = (int)value ? 1 : 0;
+    else if (k == "loopback") c->loopback = (int)value;   // 0 off, 1 device copies, 2 RCCL self send/recv
     else if (k == "pair_ty") { if (value != 8 && value != 12) return fail(LBM_ERR_ARG, "pair_ty must be 8 or 12"); c->pair_ty = (int)value; }
     else if (k == "tune") c->tune = (int)value ? 1 : 0;
     else if (k == "overlap") c->overlap = (int)value;

@@ -341,6 +341,28 @@ def test_c4_grid_8192x2048_single_gpu(lbm):
         c.close()
 
 
+def test_rccl_calls_on_a_one_rank_communicator(lbm):
+    """The production RCCL exchange (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the side stream, same counts,
+    datatype and pointers as between strips) exercised on ONE GPU: a one-rank communicator sending to itself
+    (loopback=2). Must equal the device-copy loopback bit for bit, overlapped and serialised."""
+    nx, ny, steps = 1024, 96, 151
+    kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
+    out = []
+    for loopback, overlap in ((1, 0), (2, 1), (2, 0)):
+        with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1,
+                                              loopback=loopback, overlap=overlap), **kw) as ctx:
+            if loopback == 2:
+                ctx.comm_init(0, 1, ctx.comm_unique_id())
+            ctx.initialise()
+            ctx.step(steps, 50)
+            ctx.sync()
+            out.append((ctx.populations("f_next"), ctx.drain_force_log(), ctx.first_unstable_step()))
+            if loopback == 2:
+                assert np.allclose(ctx.allreduce([1.5, -2.0], "sum"), [1.5, -2.0])      # ncclAllReduce path
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0]) and out[0][1] == other[1] and out[0][2] == other[2]
+
+
 def test_snapshot_refused_after_trailing_pair(lbm):
     with lbm.Context(128, 32, options=dict(tune=0, fuse=3, trailing_pair=1)) as ctx:
         ctx.initialise()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """tools/strip_proxy.py — how host-bound is one rank of an N-strip run? Runs a 4096 x (1024/N) strip on one GPU with the
 loopback halo transport (same host-side choreography as the RCCL path: edge launches, events, side stream; device
-copies in place of ncclSend/ncclRecv) and reports us per iteration vs the same strip without any exchange."""
+copies in place of ncclSend/ncclRecv, or RCCL send/recv to self on a one-rank communicator) and reports us per
+iteration vs the same strip without any exchange."""
 import importlib
 import os
 import sys
@@ -16,8 +17,12 @@ for n in (1, 2, 4, 8):
     line = [f"N={n} rows={rows}:"]
     for name, opts in (("no-exchange", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1)),
                        ("loopback overlap", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, loopback=1, overlap=1)),
-                       ("loopback serial", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, loopback=1, overlap=0))):
+                       ("loopback serial", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, loopback=1, overlap=0)),
+                       ("rccl-self overlap", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, loopback=2, overlap=1)),
+                       ("rccl-self serial", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, loopback=2, overlap=0))):
         with lbm.Context(nx, rows, inlet_velocity=0.05, options=opts) as c:
+            if opts.get("loopback") == 2:
+                c.comm_init(0, 1, c.comm_unique_id())      # one-rank communicator: ncclSend/ncclRecv to self
             c.initialise()
             c.step(300, 0); c.sync()
             t0 = time.perf_counter(); c.step(3000, 0); c.sync(); dt = time.perf_counter() - t0
