@@ -9,7 +9,7 @@ A "step" is one loop body of Solver::run (exchange + stream + BCs + stability + 
 launch) over the whole lattice. Workload at every N: BASELINE.json configs[2], the 4096x1024 fp64 cylinder at
 Re=200 (tau=0.6, u_in=0.06510417) — the grid the metric is quoted on ("4096x1024 D2Q9 at 1/2/4/8 GPUs"), so
 N>1 is STRONG scaling: the rows are cut into N strips, one process per GPU, edge rows exchanged with RCCL
-send/recv each step. Populations are resident in HBM before the timed region; nothing is copied to the host
+send/recv after every launch (a launch fuses up to three iterations). Populations are resident in HBM before the timed region; nothing is copied to the host
 inside it and no output (forces/VTK) step falls inside it.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (live HIP-event kernel time on
@@ -179,15 +179,15 @@ def main():
             "config": {"workload": f"D2Q9-BGK cylinder Re={args.re:g}, {nx}x{ny_total} {args.precision}, tau=0.6, "
                                    f"u_in={u_in:.8f} (BASELINE.json configs[2])",
                        "nx": nx, "ny": ny_total, "rows_per_gpu": local_ny, "decomposition": f"{world} row strip(s)",
-                       "halo": "none" if world == 1 else "RCCL send/recv, 3 populations x 1 row per face",
+                       "halo": "none" if world == 1 else "RCCL send/recv of the 3 edge rows x 9 populations per face after every launch (side stream, overlapped)",
                        "kernel": ctx.kernel_name(), "plan": ctx.plan()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": ctx.kernel_name(), "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": launch_bytes,
                          "iterations_per_launch": round(iterations / max(launches, 1), 4),
-                         "note": "achieved = algorithmic bytes (144 B per lattice update, fp64) / time; a launch that fuses two "
-                                 "iterations through LDS moves fewer HBM bytes than that, so frac can exceed 1"},
+                         "note": "achieved = algorithmic bytes (144 B per lattice update, fp64) / time; a launch that fuses several "
+                                 "iterations through LDS moves fewer HBM bytes than that (traffic = measured bytes per launch), so frac can exceed 1"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(nx, ny_total, u_in)
