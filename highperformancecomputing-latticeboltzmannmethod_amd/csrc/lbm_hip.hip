@@ -66,6 +66,7 @@ struct lbm_ctx {
     unsigned long long* d_maxbits = nullptr;
     int* d_unstable = nullptr;
     int* d_solid_count = nullptr;
+    void* d_feq = nullptr;          // the nine initial-equilibrium values in the element type (fused kernels)
     double* d_force_now = nullptr;  // 3 doubles
     double* d_force_log = nullptr;  // capacity x 3 doubles
     int log_cap = 0, log_count = 0;
@@ -177,7 +178,7 @@ void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
 template <typename T>
 void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s) {
     K2Extra<T> e;
-    for (int i = 0; i < Q; ++i) e.feq_in[i] = (T)c->feq_in[i];
+    e.feq_in = static_cast<const T*>(c->d_feq);
     const int ty = c->pair_ty;
     dim3 grid((c->nx + 63) / 64, (a.y_cnt + ty - 1) / ty + (a.y_cnt2 + ty - 1) / ty);
 #define LBM_K2(TY_, NTH_, NT_, X_) hipLaunchKernelGGL((k_step2_tile<T, TY_, NTH_, NT_, X_>), grid, dim3(NTH_), 0, s, a, e)
@@ -786,6 +787,14 @@ int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
     HIPTRY(hipMalloc(&c->d_solid_count, sizeof(int)));
     HIPTRY(hipMalloc(&c->d_maxbits, sizeof(unsigned long long)));
     HIPTRY(hipMalloc(&c->d_force_now, 3 * sizeof(double)));
+    HIPTRY(hipMalloc(&c->d_feq, Q * sizeof(double)));
+    if (p->precision == LBM_PRECISION_F32) {
+        float v[Q];
+        for (int i = 0; i < Q; ++i) v[i] = (float)c->feq_in[i];
+        HIPTRY(hipMemcpy(c->d_feq, v, sizeof(v), hipMemcpyHostToDevice));
+    } else {
+        HIPTRY(hipMemcpy(c->d_feq, c->feq_in, Q * sizeof(double), hipMemcpyHostToDevice));
+    }
     HIPTRY(hipMalloc(&c->d_force_log, 3 * sizeof(double) * c->log_cap));
     HIPTRY(hipMalloc(&c->d_halo, 4 * GR * Q * sizeof(double) * (size_t)c->nx));
     HIPTRY(hipMalloc(&c->d_red, 64 * sizeof(double)));
@@ -800,7 +809,7 @@ void lbm_destroy(lbm_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm) ncclCommDestroy(c->comm);
-    void* ptrs[] = {c->buf[0], c->buf[1], c->scratch, c->d_macro, c->d_maxbits, c->d_unstable, c->d_solid_count,
+    void* ptrs[] = {c->buf[0], c->buf[1], c->scratch, c->d_macro, c->d_maxbits, c->d_unstable, c->d_solid_count, c->d_feq,
                     c->d_force_now, c->d_force_log, c->d_halo, c->d_red};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);

@@ -293,7 +293,10 @@ __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
 // (82 B at 64x8, less when the tile halo is still in L2 / Infinity Cache). Same arithmetic per cell => results
 // bit-identical to two k_step_site launches (tests). Any nx (partial tiles at the right edge); rows of neighbouring strips must be
 // present (at least) two deep. LDS: 9*(TY+2)*(TX+4)*sizeof(T) (47.9 KB at TY=8, fp64: three blocks per CU).
-template <typename T> struct K2Extra { T feq_in[Q]; };
+// feq_in: the nine initial-equilibrium values (permanent content of physical N/S ghost rows and corner ghosts), in
+// device memory: they are needed by the few cells of a region that lie outside the domain only, and passing them by
+// value would pin 18 scalar registers for the whole kernel (the fused kernels are SGPR-bound).
+template <typename T> struct K2Extra { const T* feq_in; };
 
 template <typename T, int TY, int NTH, bool NT, bool XCD = false>
 __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Extra<T> e) {
@@ -329,15 +332,15 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
             const long c = (long)(y + GR) * a.pitch + a.xoff + x;
 #pragma unroll
             for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
-            const bool solid = near_cyl && is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+            bool solid = false;
+            if (near_cyl) solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);   // block-uniform branch
             T rho_bc, u_out;
             if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
             bad |= any_unstable(f);
-            if (solid) {
+            bgk_collide(f, a.tau_inv);
+            if (near_cyl) {                    // solid cells keep w_i (the collision result of such a cell is discarded)
 #pragma unroll
-                for (int i = 0; i < Q; ++i) f[i] = wgt<T>(i);
-            } else {
-                bgk_collide(f, a.tau_inv);
+                for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
             }
         }
 #pragma unroll
@@ -411,14 +414,16 @@ __global__ void __launch_bounds__(NTH) k_step3_tile(const KArgs<T> a, const K2Ex
             const long c = (long)(y + GR) * a.pitch + a.xoff + x;
 #pragma unroll
             for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
-            const bool solid = near_cyl && is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+            bool solid = false;
+            if (near_cyl) solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);   // block-uniform branch
             T rho_bc, u_out;
             if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
             bad |= any_unstable(f);
-            if (solid) {
+            bgk_collide(f, a.tau_inv);
+            if (near_cyl) {                    // solid cells keep w_i (the collision result of such a cell is discarded)
 #pragma unroll
-                for (int i = 0; i < Q; ++i) f[i] = wgt<T>(i);
-            } else bgk_collide(f, a.tau_inv);
+                for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
@@ -455,14 +460,16 @@ __global__ void __launch_bounds__(NTH) k_step3_tile(const KArgs<T> a, const K2Ex
         } else {
 #pragma unroll
             for (int i = 0; i < Q; ++i) f[i] = g[k][i];
-            const bool solid = near_cyl && is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+            bool solid = false;
+            if (near_cyl) solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);   // block-uniform branch
             T rho_bc, u_out;
             if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
             if (y <= y_end) bad |= any_unstable(f);
-            if (solid) {
+            bgk_collide(f, a.tau_inv);
+            if (near_cyl) {                    // solid cells keep w_i (the collision result of such a cell is discarded)
 #pragma unroll
-                for (int i = 0; i < Q; ++i) f[i] = wgt<T>(i);
-            } else bgk_collide(f, a.tau_inv);
+                for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];

@@ -215,9 +215,14 @@ void suite(int nx, int ny, long pad, int reps, int rounds, bool rowil, int pitch
     }
     {
         K2Extra<T> ex;
-        const double ux = b.u_in, usq = ux * ux, t3 = 1.5 * usq;
-        ex.feq_in[0] = (T)(wgt<double>(0) * (1.0 - 1.5 * usq));
-        for (int i = 1; i < Q; ++i) { const double cu = cx(i) * ux; ex.feq_in[i] = (T)(wgt<double>(i) * (((1.0 + 3.0 * cu) - t3) + 4.5 * cu * cu)); }
+        {
+            T hv[Q];
+            const double ux = b.u_in, usq = ux * ux, t3 = 1.5 * usq;
+            hv[0] = (T)(wgt<double>(0) * (1.0 - 1.5 * usq));
+            for (int i = 1; i < Q; ++i) { const double cu = cx(i) * ux; hv[i] = (T)(wgt<double>(i) * (((1.0 + 3.0 * cu) - t3) + 4.5 * cu * cu)); }
+            T* dv; CK(hipMalloc(&dv, sizeof(hv))); CK(hipMemcpy(dv, hv, sizeof(hv), hipMemcpyHostToDevice));
+            ex.feq_in = dv;
+        }
         auto g2 = [&](int ty) { return dim3(nx / 64, (ny + ty - 1) / ty); };
         vars.push_back({"step2 TY8 512t", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 8, 512, false>), g2(8), dim3(512), 0, s, a, ex); }, {}});
         vars.push_back({"step2 TY8 704t", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 8, 704, false>), g2(8), dim3(704), 0, s, a, ex); }, {}});
