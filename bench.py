@@ -172,7 +172,7 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "MLUPS", "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
+            "metric": f"MLUPS ({'fp64' if args.precision == 'f64' else 'fp32'})", "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
