@@ -741,6 +741,10 @@ int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
         delete c;
         return fail(LBM_ERR_ARG, "strip [%d,%d) outside [0,%d)", p->y_start, p->y_start + p->local_ny, p->ny);
     }
+    if (c->p.local_ny > 65535) {   // one grid row (grid.y) per lattice row in the single-iteration kernels
+        delete c;
+        return fail(LBM_ERR_ARG, "a strip is limited to 65535 rows (got %d): cut the domain into more strips", p->local_ny);
+    }
     c->device = device;
     c->nx = p->nx;
     c->nyl = c->p.local_ny;
