@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
 // HBM traffic per update ~ (1 + (TX+4)(TY+4)/(TX TY)) * 24 B (58 B at 64x12); redundant collisions 1.21x. Bit-identical to
 // three single launches (tests). Rows of neighbouring strips must be present three deep (GR = 3).
 template <typename T, int TY, int NTH, bool NT, bool XCD>
-__global__ void __launch_bounds__(NTH) k_step3_tile(const KArgs<T> a, const K2Extra<T> e) {
+__global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int TX = 64, R1W = TX + 4, R1H = TY + 4, R2W = TX + 2, R2H = TY + 2, LP = R1W;
     static_assert(R2W * R2H <= 2 * NTH, "two region-2 cells per thread at most");
     __shared__ T lds[Q][R1H][LP];
@@ -401,6 +401,7 @@ __global__ void __launch_bounds__(NTH) k_step3_tile(const KArgs<T> a, const K2Ex
     const bool near_cyl = tile_near_cylinder(a, X0, Y0, TX, TY, 2);
     auto outside_value = [&](bool row_in, bool col_in, int i) -> T { return (row_in && !col_in) ? T(0) : e.feq_in[i]; };
     bool bad = false;
+#pragma unroll
     for (int r = threadIdx.x; r < R1W * R1H; r += NTH) {                 // phase 1: iteration t
         const int ry = r / R1W, rx = r - ry * R1W;
         const int x = X0 + rx - 2, y = Y0 + ry - 2;

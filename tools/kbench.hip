@@ -239,6 +239,18 @@ void suite(int nx, int ny, long pad, int reps, int rounds, bool rowil, int pitch
         vars.push_back({"step2 TY12 384t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 12, 384, true, true>), g2(12), dim3(384), 0, s, a, ex); }, {}});
         vars.push_back({"step3 TY12 768t nt", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 12, 768, true, false>), g2(12), dim3(768), 0, s, a, ex); }, {}});
         vars.push_back({"step3 TY12 768t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 12, 768, true, true>), g2(12), dim3(768), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY12 576t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 12, 576, true, true>), g2(12), dim3(576), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY12 640t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 12, 640, true, true>), g2(12), dim3(640), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY12 704t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 12, 704, true, true>), g2(12), dim3(704), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY12 832t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 12, 832, true, true>), g2(12), dim3(832), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY12 896t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 12, 896, true, true>), g2(12), dim3(896), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY12 960t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 12, 960, true, true>), g2(12), dim3(960), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY12 1024t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 12, 1024, true, true>), g2(12), dim3(1024), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY10 640t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 10, 640, true, true>), g2(10), dim3(640), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY10 704t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 10, 704, true, true>), g2(10), dim3(704), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY10 512t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 10, 512, true, true>), g2(10), dim3(512), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY11 704t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 11, 704, true, true>), g2(11), dim3(704), 0, s, a, ex); }, {}});
+        vars.push_back({"step3 TY9 576t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 9, 576, true, true>), g2(9), dim3(576), 0, s, a, ex); }, {}});
         vars.push_back({"step3 TY8 512t nt", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 8, 512, true, false>), g2(8), dim3(512), 0, s, a, ex); }, {}});
         vars.push_back({"step3 TY8 512t nt xcd", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 8, 512, true, true>), g2(8), dim3(512), 0, s, a, ex); }, {}});
         vars.push_back({"step3 TY16 1024t nt", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step3_tile<T, 16, 1024, true, false>), g2(16), dim3(1024), 0, s, a, ex); }, {}});
