@@ -190,7 +190,7 @@ class Context:
         self._chk(self.L.lbm_comm_allreduce(self.h, _dp(a), a.size, {"sum": 0, "max": 1, "min": 2}[op]))
         return a
 
-    HALO_ROWS = 3   # LBM_HALO_ROWS
+    HALO_ROWS = 6   # LBM_HALO_ROWS
 
     def halo_export(self, south=True, north=True):
         """(south_out, north_out): my bottom / top HALO_ROWS interior rows, each [HALO_ROWS, 9, nx]."""

@@ -83,7 +83,9 @@ struct lbm_ctx {
     int xcd = 0;         // fused kernels: remap blocks so that each XCD walks a contiguous run of tiles
     int loopback = 0;    // TEST ONLY: the strip is its own north and south neighbour (exercises the overlap choreography):
                          // 1 = device copies, 2 = RCCL send/recv to self on a one-rank communicator
-    int trailing_pair = 0;   // allow an lbm_step call to END on a fused launch (host-staged strips: one launch per call)
+    int deep_halo = 1;       // strips: one exchange of GR rows per TWO launches (the first launch of a pair is extended)
+    int trailing_pair = 0;   // allow an lbm_step call to END on a fused launch (host-staged strips)
+    bool mid_pair = false;        // the last launch was the extended first launch of a pair (no exchange after it)
     bool last_was_pair = false;   // the last launch fused several iterations: buf[cur^1] is older than steps_done-1
     bool restored = false;   // state came from lbm_load_state: no previous-iteration buffer until the next step
     int tune = 1;        // lbm_initialise times the candidate plans on this device and keeps the fastest
@@ -345,19 +347,48 @@ int advance_with_exchange(lbm_ctx* c, int src, int dst, int t, int depth) {
     return LBM_OK;
 }
 
+inline int join_comm(lbm_ctx* c);
+
 // One launch without neighbours.
 template <typename T>
 int advance_local(lbm_ctx* c, int src, int dst, int t, int depth) {
     return launch_step<T>(c, src, dst, t, depth > 1 ? 100 + depth : MODE_STEP, c->stream);
 }
 
-// Advance by up to `remaining` iterations with ONE launch; returns the number of iterations taken (1..3) or <0.
-// d iterations are fused only when the plan allows it, when none of the iterations t+1 .. t+d-1 is a force-output
-// iteration (their post-collision states never exist in memory) and when at least one more iteration follows inside
-// this call, so that the last launch of every lbm_step call is a single iteration and buf[cur^1] holds the previous
-// iteration's populations (macro snapshot / f_current accessors).
+// EXT rows of each internal face are recomputed by the first launch of a pair (see advance).
+constexpr int EXT = 3;
+inline bool face_south(const lbm_ctx* c) { return c->p.y_start > 0 || c->loopback; }
+inline bool face_north(const lbm_ctx* c) { return c->p.y_start + c->nyl < c->p.ny || c->loopback; }
+
+// First launch of a pair: all rows of the strip PLUS the EXT ghost rows next to each internal face, one launch on the
+// main stream, no exchange afterwards. The ghost rows it reads (up to 2*EXT = GR deep) came with the last exchange.
 template <typename T>
-int advance(lbm_ctx* c, int remaining, int of, bool exchange) {
+int advance_extended(lbm_ctx* c, int src, int dst, int t, int depth) {
+    int rc = join_comm(c);          // the last exchange (and the edge bands before it) live on the side stream
+    if (rc) return rc;
+    KArgs<T> a = make_kargs<T>(c, src, dst, t);
+    const int es = face_south(c) ? EXT : 0, en = face_north(c) ? EXT : 0;
+    a.y_lo = -es;
+    a.y_cnt = c->nyl + es + en;
+    a.reverse = (c->alternate && (c->launches_total & 1)) ? 1 : 0;
+    if (depth > 1) launch_fused_rows<T>(c, a, depth, c->stream);
+    else launch_rows<T, MODE_STEP>(c, a, c->stream);
+    HIPCHK(hipGetLastError());
+    return LBM_OK;
+}
+
+// Advance by up to `remaining` iterations with ONE launch; returns the number of iterations taken (1..3) or <0.
+// Fusion: d iterations are fused only when the plan allows it, when none of the iterations t+1 .. t+d-1 is a
+// force-output iteration (their post-collision states never exist in memory) and when at least one more iteration
+// follows inside this call, so that the last launch of every lbm_step call is a single iteration and buf[cur^1] holds
+// the previous iteration's populations (macro snapshot / f_current accessors).
+// Strips: launches come in pairs between halo exchanges. The first launch of a pair is "extended" (advance_extended,
+// no exchange after it), the second is a normal launch followed by the exchange of GR rows; the last launch of a
+// call is never a first one, so every call ends with valid ghost rows. Every rank derives the same sequence from
+// (steps_done, remaining, output_frequency). Without a device transport (host-staged halos: the caller exchanges
+// after every call) a call may therefore contain at most two launches.
+template <typename T>
+int advance(lbm_ctx* c, int remaining, int of, bool transport, bool strip_logic = true) {
     const int t = c->steps_done;
     int depth = 1;
     if (c->fuse > 1 && pair_possible(c)) {
@@ -368,8 +399,20 @@ int advance(lbm_ctx* c, int remaining, int of, bool exchange) {
             if (ok) depth = d;
         }
     }
+    const bool faces = strip_logic && (face_south(c) || face_north(c));
+    const bool last = remaining - depth <= 0;
     const int src = c->cur, dst = c->cur ^ 1;
-    int rc = exchange ? advance_with_exchange<T>(c, src, dst, t, depth) : advance_local<T>(c, src, dst, t, depth);
+    int rc;
+    if (faces && c->deep_halo && !last && !c->mid_pair) {
+        rc = advance_extended<T>(c, src, dst, t, depth);
+        c->mid_pair = true;
+    } else {
+        if (faces && !transport && !last)
+            return fail(LBM_ERR_ARG, "a strip with host-staged halos can take at most two launches per lbm_step call "
+                                     "(exchange the edge rows, then call again)");
+        rc = transport ? advance_with_exchange<T>(c, src, dst, t, depth) : advance_local<T>(c, src, dst, t, depth);
+        c->mid_pair = false;
+    }
     if (rc) return rc;
     c->cur = dst;
     c->steps_done = t + depth;
@@ -439,7 +482,8 @@ int time_plan(lbm_ctx* c, float* ms_out) {
     if (rc) return rc;
     auto run = [&](int n) -> int {
         for (int k = 0; k < n;) {
-            const int took = advance<T>(c, n - k + 3, 0, false);   // +3: never end on the "last is single" rule
+            const int took = advance<T>(c, n - k + 3, 0, false, false);   // +3: never end on the "last is single" rule;
+                                                                          // no strip logic: the probe times local launches
             if (took < 0) return took;
             k += took;
         }
@@ -562,7 +606,7 @@ int do_steps(lbm_ctx* c, int nsteps, int of) {
             if (rc) return rc;
             c->log_count++;
         }
-        const int took = advance<T>(c, nsteps - k, of, exchange);
+        const int took = advance<T>(c, nsteps - k, of, exchange);   // exchange == a device transport is attached
         if (took < 0) return took;
         k += took;
         ++launches;
@@ -1049,6 +1093,7 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "pair") c->fuse = (int)value ? 2 : 1;
     else if (k == "trailing_pair") c->trailing_pair = (int)value ? 1 : 0;
     else if (k == "xcd") c->xcd = (int)value ? 1 : 0;
+    else if (k == "deep_halo") c->deep_halo = (int)value ? 1 : 0;
     else if (k == "loopback") c->loopback = (int)value;   // 0 off, 1 device copies, 2 RCCL self send/recv
     else if (k == "pair_ty") { if (value != 8 && value != 12) return fail(LBM_ERR_ARG, "pair_ty must be 8 or 12"); c->pair_ty = (int)value; }
     else if (k == "tune") c->tune = (int)value ? 1 : 0;

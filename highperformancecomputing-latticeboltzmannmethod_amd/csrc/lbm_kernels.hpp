@@ -5,8 +5,9 @@
 //
 //     plane i, local row gy in [0, ny_loc+2*GR), column col:   base[i*plane + gy*pitch + col]
 //     interior cell (x, y)  <->  gy = y+GR, col = xoff + x      (xoff*sizeof(T) is a multiple of 128 B)
-// GR = 3 ghost rows on each side (a launch that fuses up to three iterations recomputes up to two of a neighbouring
-// strip's rows and needs its three edge rows); one ghost column on each side.
+// GR = 6 ghost rows on each side (strips exchange their six edge rows once per TWO launches of up to three fused
+// iterations: the first launch of such a pair also updates three ghost rows per internal face, redundantly with the
+// neighbour, so that the second one finds valid inputs); one ghost column on each side.
 // The two strides describe either of two layouts chosen by the host (lbm_hip.hip, "plan"):
 //     PLANAR          plane = rows*pitch0 (+pad), pitch = pitch0            nine separate planes
 //     ROW-INTERLEAVED plane = pitch0,             pitch = 9*pitch0          [gy][i][col]: the nine sub-rows of a
@@ -38,7 +39,8 @@
 namespace lbmk {
 
 constexpr int Q = 9;
-constexpr int GR = 3;   // ghost rows below and above the strip (= the deepest fusion: three iterations per launch)
+constexpr int GR = 6;   // ghost rows below and above the strip: two launches of up to three iterations each between
+                        // halo exchanges (the first one recomputes three of the neighbour's rows on each side)
 // LBMConfig.h:13-34 — direction numbering is observable through f_current(x,y,i), keep it.
 __host__ __device__ constexpr int cx(int i) { constexpr int v[Q] = {0, 1, 0, -1, 0, 1, -1, -1, 1}; return v[i]; }
 __host__ __device__ constexpr int cy(int i) { constexpr int v[Q] = {0, 0, 1, 0, -1, 1, 1, -1, -1}; return v[i]; }
@@ -381,7 +383,7 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
 //            registers, barrier, then computes P_{t+2} and writes it IN PLACE (no second LDS image);
 //   phase 3  the tile: pull P_{t+2} from LDS, BCs, collide, store P_{t+3}.
 // HBM traffic per update ~ (1 + (TX+4)(TY+4)/(TX TY)) * 24 B (58 B at 64x12); redundant collisions 1.21x. Bit-identical to
-// three single launches (tests). Rows of neighbouring strips must be present three deep (GR = 3).
+// three single launches (tests). Rows of neighbouring strips must be present three deep beyond the rows written.
 template <typename T, int TY, int NTH, bool NT, bool XCD>
 __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int TX = 64, R1W = TX + 4, R1H = TY + 4, R2W = TX + 2, R2H = TY + 2, LP = R1W;

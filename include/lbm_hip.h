@@ -108,14 +108,16 @@ int  lbm_comm_init(lbm_ctx* c, int rank, int nranks, const void* id128);
  * LBMIO.h:167-168, LBMGrid.h:315,342). In place, host values, n doubles. op: 0 sum, 1 max, 2 min. */
 int  lbm_comm_allreduce(lbm_ctx* c, double* vals, int n, int op);
 /* Host-staged path (the buffers the reference hands to MPI_Isend/Irecv, LBMGrid.h:255-276). Each face buffer is
- * [LBM_HALO_ROWS][9][nx] doubles: the LBM_HALO_ROWS (= 3) interior rows next to that face, bottom row first, all nine
- * populations (three rows because a launch may fuse up to three iterations and recomputes the neighbour's edge rows).
+ * [LBM_HALO_ROWS][9][nx] doubles: the LBM_HALO_ROWS (= 6) interior rows next to that face, bottom row first, all nine
+ * populations (six rows: up to two launches of up to three fused iterations each may run between two exchanges, the
+ * first one recomputing three of the neighbour's rows).
  * export: south_out = my bottom rows, north_out = my top rows; import: south_in -> my south ghost rows (= the south
  * neighbour's north_out), north_in -> my north ghost rows. NULL = that side is a physical wall. The caller exchanges
- * after lbm_initialise and after EVERY lbm_step call, and calls lbm_step so that it issues ONE launch (nsteps = 1, or
- * nsteps = 2 / 3 with the options "fuse" >= nsteps and "trailing_pair" 1 and no force-output iteration inside). Used by
+ * after lbm_initialise and after EVERY lbm_step call, and calls lbm_step so that it issues at most TWO launches
+ * (e.g. nsteps <= 4 by default = a fused launch of three iterations + a single one, or nsteps = 6 with the option
+ * "trailing_pair" 1; lbm_step refuses a call that would need a third launch). Used by
  * MPI-hosted callers and by the 2-rank tests. */
-#define LBM_HALO_ROWS 3
+#define LBM_HALO_ROWS 6
 int  lbm_halo_export(lbm_ctx* c, double* south_out, double* north_out);
 int  lbm_halo_import(lbm_ctx* c, const double* south_in, const double* north_in);
 

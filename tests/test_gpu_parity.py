@@ -280,15 +280,17 @@ def test_overlap_choreography_with_loopback_halo(lbm, pair):
     nx, ny, steps = 1024, 96, 301
     kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
     out = []
-    for overlap in (0, 1):
+    # deep_halo=0: one exchange after every launch; deep_halo=1: one per two launches (the first one extended)
+    for overlap, deep in ((0, 0), (0, 1), (1, 1), (1, 0)):
         with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, fuse=pair, pair_ty=12, xcd=1,
-                                              loopback=1, overlap=overlap), **kw) as ctx:
+                                              loopback=1, overlap=overlap, deep_halo=deep), **kw) as ctx:
             ctx.initialise()
             ctx.step(steps, 50)
             ctx.sync()
             out.append((ctx.populations("f_next"), ctx.drain_force_log(), ctx.first_unstable_step()))
-    assert np.array_equal(out[0][0], out[1][0])
-    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0])
+        assert out[0][1] == other[1] and out[0][2] == other[2]
 
 
 def test_checkpoint_restart_is_bit_exact(lbm, tmp_path):
@@ -361,6 +363,52 @@ def test_rccl_calls_on_a_one_rank_communicator(lbm):
                 assert np.allclose(ctx.allreduce([1.5, -2.0], "sum"), [1.5, -2.0])      # ncclAllReduce path
     for other in out[1:]:
         assert np.array_equal(out[0][0], other[0]) and out[0][1] == other[1] and out[0][2] == other[2]
+
+
+def test_strips_two_launches_per_exchange_match_single_domain_bitwise(lbm):
+    """Host-staged strips exchanging their LBM_HALO_ROWS edge rows once per TWO launches (6 iterations): the first
+    launch of each call also recomputes three ghost rows per internal face. == the one-domain run, bit for bit."""
+    nx, ny, of = 192, 90, 12
+    calls = 14
+    steps = 6 * calls + 1
+    kw = dict(inlet_velocity=0.06, cylinder_radius=0.12)
+    with lbm.Context(nx, ny, options=PLANS["planar-site"], **kw) as whole:
+        whole.initialise()
+        whole.step(steps, of)
+        w = whole.macros()
+        w_fn = whole.populations("f_next")
+        w_log = whole.drain_force_log()
+    bounds = [(0, 31), (31, 14), (45, 45)]
+    plans = ["planar-fuse3-8", "rowil-fuse3-12-nt-xcd", "rowil-fuse3-12-nt-xcd"]
+    ctxs = [lbm.Context(nx, ny, y_start=y0, local_ny=n, options=dict(PLANS[pl], trailing_pair=1), **kw)
+            for (y0, n), pl in zip(bounds, plans)]
+    for c in ctxs:
+        c.initialise()
+
+    def exchange():
+        ex = [c.halo_export(south=(k > 0), north=(k < len(ctxs) - 1)) for k, c in enumerate(ctxs)]
+        for k, c in enumerate(ctxs):
+            c.halo_import(south=ex[k - 1][1] if k > 0 else None, north=ex[k + 1][0] if k < len(ctxs) - 1 else None)
+    exchange()
+    for _ in range(calls):
+        for c in ctxs:
+            c.step(6, of)           # [3 iterations, extended][3 iterations] — of = 12 falls on call boundaries
+        exchange()
+    for c in ctxs:
+        c.step(1, of)
+    exchange()
+    parts = [c.macros() for c in ctxs]
+    for j in range(3):
+        assert np.array_equal(np.concatenate([p[j] for p in parts], axis=0), w[j])
+    assert np.array_equal(np.concatenate([c.populations("f_next")[1:-1] for c in ctxs], axis=0), w_fn[1:-1])
+    logs = [c.drain_force_log() for c in ctxs]
+    assert [r[0] for r in logs[0]] == [r[0] for r in w_log]
+    for k, (tt, fx, fy) in enumerate(w_log):
+        assert abs(sum(l[k][1] for l in logs) - fx) <= 1e-13 * max(1.0, abs(fx))
+    with pytest.raises(lbm.LbmError, match="at most two launches"):
+        ctxs[1].step(9, 0)          # a third launch would need fresh ghost rows
+    for c in ctxs:
+        c.close()
 
 
 def test_snapshot_refused_after_trailing_pair(lbm):
