@@ -34,14 +34,14 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 BYTES_PER_LUP = {"f64": 144, "f32": 72}   # 9 loads + 9 stores per lattice update
 
 
-def _time_reference(ref, d, nx, ny, u_in, steps, ranks, threads):
+def _time_reference(ref, d, nx, ny, u_in, steps, ranks, threads, timeout=120):
     """One timed run of the unmodified reference: `ranks` MPI ranks (mpiexec) x `threads` OpenMP threads."""
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
     cmd = [ref, "--nx", str(nx), "--ny", str(ny), "--steps", str(steps), "--of", "1000000", "--tau", "0.6",
            "--u", repr(u_in), "--time"]
     if ranks > 1:
         cmd = [MPIEXEC, "-n", str(ranks)] + cmd
-    out = subprocess.run(cmd, cwd=d, env=env, timeout=300, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    out = subprocess.run(cmd, cwd=d, env=env, timeout=timeout, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     m = re.search(r"REFTIME .*ranks=(\d+) threads=(\d+) seconds=([\d.]+) mlups=([\d.]+) ok=1", out.stdout)
     if not m or int(m.group(1)) != ranks:
         raise RuntimeError((out.stderr or out.stdout)[-300:])
@@ -70,7 +70,7 @@ def cpu_baseline(nx, ny, u_in, budget_s=12.0):
             probe = {}
             for r, t in splits:
                 try:
-                    probe[(r, t)] = _time_reference(ref, d, nx, ny, u_in, 8, r, t)
+                    probe[(r, t)] = _time_reference(ref, d, nx, ny, u_in, 8, r, t, timeout=40)
                 except Exception:
                     pass
             (ranks, threads) = max(probe, key=probe.get)
