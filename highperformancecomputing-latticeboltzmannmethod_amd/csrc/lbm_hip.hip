@@ -874,6 +874,8 @@ int lbm_initialise(lbm_ctx* c, int* solid_count_out) {
     HIPCHK(hipSetDevice(c->device));
     c->steps_done = 0;
     c->log_count = 0;
+    c->mid_pair = false;
+    c->comm_issued = false;
     if (c->scratch) { (void)hipFree(c->scratch); c->scratch = nullptr; }
     int rc = DISPATCH(c, do_initialise<double>(c), do_initialise<float>(c));
     if (rc) return rc;
@@ -1075,6 +1077,7 @@ int lbm_load_state(lbm_ctx* c, const char* path) {
     if (rc) return rc;
     c->log_count = 0;
     c->last_was_pair = false;
+    c->mid_pair = false;
     if (c->comm || c->loopback) rc = DISPATCH(c, exchange_rccl<double>(c, c->cur, c->stream), exchange_rccl<float>(c, c->cur, c->stream));
     return rc;
 }
