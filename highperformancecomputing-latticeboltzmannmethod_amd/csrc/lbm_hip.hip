@@ -872,6 +872,8 @@ void lbm_destroy(lbm_ctx* c) {
 int lbm_initialise(lbm_ctx* c, int* solid_count_out) {
     if (!c) return fail(LBM_ERR_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));        // (re-)initialisation starts from quiet streams
+    HIPCHK(hipStreamSynchronize(c->comm_stream));
     c->steps_done = 0;
     c->log_count = 0;
     c->mid_pair = false;
