@@ -57,7 +57,8 @@ typedef struct lbm_force_row { int timestep; double fx, fy; } lbm_force_row;
 const char* lbm_last_error(void);
 int  lbm_device_count(void);
 
-/* Grid::Grid (LBMGrid.h:57-90): allocates the SoA population planes (2 buffers), macro scratch, logs. */
+/* Grid::Grid (LBMGrid.h:57-90): creates the context (streams, logs); the two SoA population buffers are allocated by
+ * lbm_initialise, whose measured plan decides their layout. */
 int  lbm_create(const lbm_params* p, int device, lbm_ctx** out);
 void lbm_destroy(lbm_ctx* c);
 
@@ -66,11 +67,13 @@ void lbm_destroy(lbm_ctx* c);
 int  lbm_initialise(lbm_ctx* c, int* solid_count_out);
 
 /* `nsteps` loop bodies of Solver::run (LBMSolver.h:49-60): exchange + stream + BCs + stability of iteration
- * t, fused with collision_step() of iteration t+1, one kernel launch per step. Asynchronous on the context's
- * stream. If output_frequency > 0, record_forces is evaluated on-device for every t % output_frequency == 0
- * inside the range (LBMSolver.h:52-54) and appended to the force log. With a communicator attached
- * (lbm_comm_init) each step also exchanges the strip's edge rows (replaces Grid::exchange_ghost_cells,
- * LBMGrid.h:249-283). */
+ * t, fused with collision_step() of iteration t+1; up to three consecutive iterations share one kernel launch
+ * (intermediate states stay in LDS; results are bit-identical to one launch per iteration). Asynchronous on the
+ * context's streams. If output_frequency > 0, record_forces is evaluated on-device for every
+ * t % output_frequency == 0 inside the range (LBMSolver.h:52-54) and appended to the force log. The last iteration
+ * of a call is always a launch of its own, so that the snapshots below refer to iteration steps_done-1. With a
+ * communicator attached (lbm_comm_init) the strip's edge rows are exchanged once per two launches (replaces
+ * Grid::exchange_ghost_cells, LBMGrid.h:249-283). */
 int  lbm_step(lbm_ctx* c, int nsteps, int output_frequency);
 
 int  lbm_sync(lbm_ctx* c);
@@ -99,9 +102,10 @@ int  lbm_get_populations(lbm_ctx* c, int which, double* aos);
 int  lbm_get_solid(lbm_ctx* c, unsigned char* mask);
 
 /* ---- strip halo exchange (replaces Grid::exchange_ghost_cells, LBMGrid.h:249-283) ----
- * Device path: RCCL send/recv of the LBM_HALO_ROWS edge rows per face (one contiguous run in the row-interleaved layout) after
- * every launch, on a side stream, overlapped with the interior update. `unique_id` is the 128-byte ncclUniqueId produced by
- * lbm_comm_unique_id on rank 0 and distributed by the launcher. Ranks are ordered bottom (0) to top. */
+ * Device path: RCCL send/recv of the LBM_HALO_ROWS edge rows per face (one contiguous run in the row-interleaved
+ * layout) once per two launches, on a side stream, overlapped with the interior update. `id128` is the 128-byte
+ * ncclUniqueId produced by lbm_comm_unique_id on rank 0 and distributed by the launcher. Ranks are ordered bottom (0)
+ * to top; attach the communicator before lbm_initialise. */
 int  lbm_comm_unique_id(void* id128);
 int  lbm_comm_init(lbm_ctx* c, int rank, int nranks, const void* id128);
 /* Sum the partial force sums / max / min across strips (the reference's MPI_Reduce/MPI_Allreduce at
@@ -140,7 +144,7 @@ int  lbm_set_option(lbm_ctx* c, const char* key, long value);
  * the last lbm_step call; 0 if events were not enabled via lbm_set_option(c, "timing", 1). */
 int  lbm_last_step_kernel_ms(lbm_ctx* c, double* ms_per_launch);
 /* Same measurement, unreduced: device milliseconds of the last lbm_step call, the step-kernel launches it issued and
- * the iterations it advanced (a two-step launch advances two). */
+ * the iterations it advanced (a fused launch advances two or three). */
 int  lbm_last_step_stats(lbm_ctx* c, double* ms_total, int* launches, int* iterations);
 const char* lbm_kernel_name(const lbm_ctx* c);
 /* The plan lbm_initialise settled on (layout / kernel / store policy / traversal), for logs. */
