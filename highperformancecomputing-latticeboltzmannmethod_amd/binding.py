@@ -67,12 +67,18 @@ def lib():
         L.lbm_last_step_stats.argtypes = [vp, dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.lbm_kernel_name.argtypes = [vp]; L.lbm_kernel_name.restype = C.c_char_p
         L.lbm_plan.argtypes = [vp]; L.lbm_plan.restype = C.c_char_p
+        L.lbm_build_id.restype = C.c_char_p
         _lib = L
     return _lib
 
 
 def device_count():
     return lib().lbm_device_count()
+
+
+def build_id():
+    """Source hash the loaded library was compiled from (lbm_build_id)."""
+    return lib().lbm_build_id().decode()
 
 
 def _dp(a):

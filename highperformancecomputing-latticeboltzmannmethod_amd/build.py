@@ -1,5 +1,11 @@
-"""Builds csrc/liblbm_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+"""Builds csrc/liblbm_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+The library carries the SHA-256 of its own sources (csrc/* and include/lbm_hip.h) as `lbm_build_id()`; build_all()
+rebuilds whenever the id embedded in the .so on disk differs from the hash of the sources in the tree, so a stale
+binary (the .so is git-ignored but travels with the working tree) can never be mistaken for HEAD."""
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 
@@ -7,26 +13,49 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liblbm_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+_MARK = b"LBM_BUILD_ID="
 
 
-def _newer(target, sources):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+def _sources():
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
+    srcs.append(os.path.join(os.path.dirname(HERE), "include", "lbm_hip.h"))
+    return srcs
+
+
+def source_id():
+    """SHA-256 (first 16 hex digits) over the names and contents of the library's sources."""
+    h = hashlib.sha256()
+    for s in _sources():
+        h.update(os.path.basename(s).encode() + b"\0")
+        with open(s, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
+def embedded_id(path=LIB):
+    """The id baked into a built library (read from the file, no dlopen), or None."""
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as f:
+        m = re.search(_MARK + rb"([0-9a-f]{16})", f.read())
+    return m.group(1).decode() if m else None
 
 
 def build_all(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h"))]
-    srcs.append(os.path.join(os.path.dirname(HERE), "include", "lbm_hip.h"))
-    if force or _newer(LIB, srcs):
+    want = source_id()
+    if force or embedded_id() != want:
         # -ffp-contract=off: no fused multiply-add is formed behind the source's back, so every formulation of the
-        # step kernel (site / vector, any layout) and the strict-IEEE oracle evaluate the same operation sequence
+        # step kernel (site / vector / fused, any layout) and the strict-IEEE oracle evaluate the same operation sequence
+        tmp = LIB + ".tmp"
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", "-shared",
-               "-o", LIB, os.path.join(CSRC, "lbm_hip.hip"),
+               "-DLBM_BUILD_ID_STR=\"" + want + "\"",
+               "-o", tmp, os.path.join(CSRC, "lbm_hip.hip"),
                "-L" + os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+        assert embedded_id() == want, "the built library does not carry the expected build id"
     return LIB

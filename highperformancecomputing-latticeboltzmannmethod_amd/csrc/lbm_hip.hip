@@ -81,6 +81,10 @@ struct lbm_ctx {
     int fuse = 1;        // iterations fused per launch where the schedule allows: 1, 2 (k_step2_tile) or 3 (k_step3_tile)
     int pair_ty = 8;     // tile height of the fused kernels (8 or 12)
     int xcd = 0;         // fused kernels: remap blocks so that each XCD walks a contiguous run of tiles
+    int slide = 0;       // fused launches use the sliding-window kernel k_step_slide (column blocks marching in y)
+    int arith = 0;       // collision arithmetic: 0 strict IEEE op-by-op (bit-identical to the oracle), 1 contracted (FMA +
+                         // one reciprocal, as the reference's -ffast-math -mfma build permits); see lbm_kernels.hpp Arith
+    int num_cus = 256;   // compute units of the device (k_step_slide sizes its segments so that all blocks are resident)
     int loopback = 0;    // TEST ONLY: the strip is its own north and south neighbour (exercises the overlap choreography):
                          // 1 = device copies, 2 = RCCL send/recv to self on a one-rank communicator
     int deep_halo = 1;       // strips: one exchange of GR rows per TWO launches (the first launch of a pair is extended)
@@ -165,14 +169,26 @@ template <typename T, int MODE>
 void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
     constexpr int V = vec_width<T>();
     const bool nt = (MODE == MODE_STEP) && c->use_nt;
+    const bool fast = (MODE != MODE_STREAM_ONLY) && c->arith == AR_CONTRACTED;   // (the stream-only snapshot has no collision)
+    constexpr int AF = (MODE == MODE_STREAM_ONLY) ? AR_STRICT : AR_CONTRACTED;
     if (use_vec(c)) {
         dim3 grid((c->nx / V + 255) / 256, a.y_cnt + a.y_cnt2), block(256);
-        if (nt) hipLaunchKernelGGL((k_step_vec<T, V, MODE, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_step_vec<T, V, MODE, false>), grid, block, 0, s, a);
+        if (fast) {
+            if (nt) hipLaunchKernelGGL((k_step_vec<T, V, MODE, true, AF>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_step_vec<T, V, MODE, false, AF>), grid, block, 0, s, a);
+        } else {
+            if (nt) hipLaunchKernelGGL((k_step_vec<T, V, MODE, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_step_vec<T, V, MODE, false>), grid, block, 0, s, a);
+        }
     } else {
         dim3 grid((c->nx + 255) / 256, a.y_cnt + a.y_cnt2), block(256);
-        if (nt) hipLaunchKernelGGL((k_step_site<T, MODE, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_step_site<T, MODE, false>), grid, block, 0, s, a);
+        if (fast) {
+            if (nt) hipLaunchKernelGGL((k_step_site<T, MODE, true, AF>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_step_site<T, MODE, false, AF>), grid, block, 0, s, a);
+        } else {
+            if (nt) hipLaunchKernelGGL((k_step_site<T, MODE, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_step_site<T, MODE, false>), grid, block, 0, s, a);
+        }
     }
 }
 
@@ -181,6 +197,33 @@ template <typename T>
 void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s) {
     K2Extra<T> e;
     e.feq_in = static_cast<const T*>(c->d_feq);
+    if (c->slide) {
+        // Column blocks of 64 cells marching up segments of seg_h rows in bands of SB rows. Segments are sized so that
+        // every block of the launch is resident at once (two blocks per CU): one wave of blocks, no tail.
+        constexpr int SB = 6;
+        SlideArgs sa;
+        sa.ncol = (c->nx + 63) / 64;
+        const int rows = a.y_cnt + a.y_cnt2;
+        const int want = std::max(1, 2 * c->num_cus / sa.ncol);
+        sa.seg_h = std::max(round_up((rows + want - 1) / want, SB), 2 * SB);
+        sa.nseg1 = (a.y_cnt + sa.seg_h - 1) / sa.seg_h;
+        sa.nseg2 = (a.y_cnt2 + sa.seg_h - 1) / sa.seg_h;
+        dim3 grid(sa.ncol * (sa.nseg1 + sa.nseg2)), block((SB + 1) * 64);
+#define LBM_KS(D_, NT_, AR_) hipLaunchKernelGGL((k_step_slide<T, D_, SB, NT_, AR_>), grid, block, 0, s, a, e, sa)
+        const int sel = (depth == 3 ? 4 : 0) + (c->use_nt ? 2 : 0) + (c->arith == AR_CONTRACTED ? 1 : 0);
+        switch (sel) {
+            case 0: LBM_KS(2, false, AR_STRICT); break;
+            case 1: LBM_KS(2, false, AR_CONTRACTED); break;
+            case 2: LBM_KS(2, true, AR_STRICT); break;
+            case 3: LBM_KS(2, true, AR_CONTRACTED); break;
+            case 4: LBM_KS(3, false, AR_STRICT); break;
+            case 5: LBM_KS(3, false, AR_CONTRACTED); break;
+            case 6: LBM_KS(3, true, AR_STRICT); break;
+            default: LBM_KS(3, true, AR_CONTRACTED); break;
+        }
+#undef LBM_KS
+        return;
+    }
     const int ty = c->pair_ty;
     dim3 grid((c->nx + 63) / 64, (a.y_cnt + ty - 1) / ty + (a.y_cnt2 + ty - 1) / ty);
 #define LBM_K2(TY_, NTH_, NT_, X_) hipLaunchKernelGGL((k_step2_tile<T, TY_, NTH_, NT_, X_>), grid, dim3(NTH_), 0, s, a, e)
@@ -323,7 +366,7 @@ int advance_with_exchange(lbm_ctx* c, int src, int dst, int t, int depth) {
         HIPCHK(hipGetLastError());
         return exchange_rccl<T>(c, dst, c->stream);
     }
-    const int E = depth > 1 ? c->pair_ty : GR;
+    const int E = depth > 1 ? (c->slide ? GR : c->pair_ty) : GR;   // one tile band / one band of the sliding kernel
     int e0 = has_s ? E : 0, e1 = has_n ? E : 0;
     if (e0 + e1 >= c->nyl) { e0 = c->nyl; e1 = 0; }          // short strip: everything is edge
     HIPCHK(hipEventRecord(c->ev_main, c->stream));
@@ -468,12 +511,18 @@ inline int alloc_buffers(lbm_ctx* c) {
 // 4096x1024 fp64 depending on the allocation). All candidates compute bit-identical results, so lbm_initialise
 // times each one on the real buffers (8 warm-up + 24 timed launches, a few ms) and keeps the fastest together
 // with the very allocation it was measured on.
-struct Plan { int layout, variant, nt, alternate, fuse, ty, xcd; const char* name; };
+struct Plan { int layout, variant, nt, alternate, fuse, ty, xcd; const char* name; int slide = 0; };
 
 inline void apply_plan(lbm_ctx* c, const Plan& pl) {
     configure_layout(c, pl.layout);
     c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate; c->fuse = pl.fuse > 0 ? pl.fuse : 1; c->xcd = pl.xcd;
     if (pl.ty) c->pair_ty = pl.ty;
+    c->slide = pl.slide;
+    if (c->arith == AR_CONTRACTED && c->fuse > 1) c->slide = 1;   // the tile kernels exist in strict arithmetic only
+    if (c->slide && c->total * c->esize >= (size_t(1) << 32)) {   // k_step_slide addresses a buffer with 32-bit byte offsets
+        c->slide = 0;
+        if (c->arith == AR_CONTRACTED) c->fuse = 1;
+    }
 }
 
 template <typename T>
@@ -506,7 +555,7 @@ template <typename T>
 int choose_plan(lbm_ctx* c) {
     const bool strips = c->comm && c->nranks > 1;
     const Plan fixed = {(strips || c->loopback) ? 1 : c->layout, c->variant, c->use_nt, c->alternate, c->fuse, c->pair_ty, c->xcd,
-                        "fixed by options"};
+                        "fixed by options", c->slide};
     std::vector<Plan> cand;
     const bool vec_ok = (c->nx % vec_width<T>() == 0), p2 = pair_possible(c);
     size_t free_b = 0, total_b = 0;
@@ -525,10 +574,14 @@ int choose_plan(lbm_ctx* c) {
         // fixed by rule (3 iterations, 64x12 tiles); only rank-local choices are measured.
         if (strips) {
             const int f = p2 ? 3 : 1;
+            if (p2) cand.push_back({1, 1, 1, 0, f, 12, 1, "row-interleaved/3-step sliding 64-column/nt-store", 1});
+            if (p2) cand.push_back({1, 1, 0, 0, f, 12, 1, "row-interleaved/3-step sliding 64-column", 1});
             cand.push_back({1, 1, 1, 0, f, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
             cand.push_back({1, 1, 1, 0, f, 12, 0, "row-interleaved/3-step 64x12/nt-store"});
             cand.push_back({1, 1, 0, 1, f, 12, 1, "row-interleaved/3-step 64x12/alternate/xcd"});
         } else {
+            if (p2) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step sliding 64-column/nt-store", 1});
+            if (p2) cand.push_back({1, 1, 0, 0, 3, 12, 1, "row-interleaved/3-step sliding 64-column", 1});
             if (p2) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
             if (p2) cand.push_back({1, 1, 1, 0, 3, 8, 1, "row-interleaved/3-step 64x8/nt-store/xcd"});
             if (p2) cand.push_back({1, 1, 1, 0, 2, 12, 1, "row-interleaved/2-step 64x12/nt-store/xcd"});
@@ -537,6 +590,8 @@ int choose_plan(lbm_ctx* c) {
             cand.push_back({1, 1, 0, 1, 1, 0, 0, "row-interleaved/site/alternate"});
         }
         if (!strips) {
+            if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 1, "planar/3-step sliding 64-column/nt-store", 1});
+            if (p2) cand.push_back({0, 0, 0, 0, 3, 12, 1, "planar/3-step sliding 64-column", 1});
             if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 1, "planar/3-step 64x12/nt-store/xcd"});
             if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 0, "planar/3-step 64x12/nt-store"});
             if (p2) cand.push_back({0, 0, 1, 0, 2, 12, 0, "planar/2-step 64x12/nt-store"});
@@ -545,18 +600,26 @@ int choose_plan(lbm_ctx* c) {
             cand.push_back({0, 1, 0, 1, 1, 0, 0, "planar/site/alternate"});
         }
     }
+    if (c->arith == AR_CONTRACTED && cand.size() > 1) {   // the tile kernels exist in strict arithmetic only
+        std::vector<Plan> keep;
+        for (const Plan& pl : cand)
+            if (pl.fuse <= 1 || pl.slide) keep.push_back(pl);
+        cand.swap(keep);
+    }
+    free_buffers(c);                                // a second lbm_initialise starts from no population buffers
     void* best_buf[2] = {nullptr, nullptr};
     float best_ms = 1e30f;
     int best = -1;
+    auto drop_best = [&]() { for (void*& q : best_buf) if (q) { (void)hipFree(q); q = nullptr; } };
     for (size_t k = 0; k < cand.size(); ++k) {
         apply_plan(c, cand[k]);
         c->buf[0] = c->buf[1] = nullptr;            // keep the best allocation alive while the next one is probed
         int rc = alloc_buffers(c);
-        if (rc) { c->buf[0] = best_buf[0]; c->buf[1] = best_buf[1]; return rc; }
+        if (rc) { free_buffers(c); drop_best(); return rc; }
         float ms = 0.f;
         if (cand.size() > 1) {
             rc = time_plan<T>(c, &ms);
-            if (rc) return rc;
+            if (rc) { free_buffers(c); drop_best(); return rc; }
         }
         if (ms < best_ms) {
             for (void* q : best_buf) if (q) (void)hipFree(q);
@@ -819,6 +882,10 @@ int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
             return bail(fail(LBM_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)));  \
     } while (0)
     HIPTRY(hipSetDevice(device));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
+    }
     HIPTRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     {   // the side stream carries the edge bands + exchange, which sit on the critical path: highest priority
         int lo = 0, hi = 0;
@@ -1065,6 +1132,15 @@ int lbm_save_state(lbm_ctx* c, const char* path) {
 int lbm_load_state(lbm_ctx* c, const char* path) {
     if (!c || !c->initialised || !path) return fail(LBM_ERR_ARG, "lbm_load_state needs an initialised context");
     HIPCHK(hipSetDevice(c->device));
+    // the state is replaced wholesale: nothing of the run so far may still be in flight on either stream
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->comm_stream));
+    c->comm_issued = false;
+    {
+        const int big = INT_MAX;
+        HIPCHK(hipMemcpyAsync(c->d_unstable, &big, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     FILE* fp = fopen(path, "rb");
     if (!fp) return fail(LBM_ERR_ARG, "cannot open %s", path);
     CkptHeader h{};
@@ -1087,7 +1163,7 @@ int lbm_load_state(lbm_ctx* c, const char* path) {
 int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     if (!c || !key) return fail(LBM_ERR_ARG, "null argument");
     const std::string k(key);
-    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune" || k == "pair" || k == "fuse" || k == "pair_ty" || k == "loopback"))
+    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune" || k == "pair" || k == "fuse" || k == "pair_ty" || k == "loopback" || k == "slide" || k == "arith"))
         return fail(LBM_ERR_ARG, "option %s must be set before lbm_initialise", key);
     if (k == "variant") c->variant = (int)value;
     else if (k == "timing") c->timing = (int)value;
@@ -1098,6 +1174,8 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "pair") c->fuse = (int)value ? 2 : 1;
     else if (k == "trailing_pair") c->trailing_pair = (int)value ? 1 : 0;
     else if (k == "xcd") c->xcd = (int)value ? 1 : 0;
+    else if (k == "slide") c->slide = (int)value ? 1 : 0;
+    else if (k == "arith") { if (value != 0 && value != 1) return fail(LBM_ERR_ARG, "arith must be 0 (strict) or 1 (contracted)"); c->arith = (int)value; }
     else if (k == "deep_halo") c->deep_halo = (int)value ? 1 : 0;
     else if (k == "loopback") c->loopback = (int)value;   // 0 off, 1 device copies, 2 RCCL self send/recv
     else if (k == "pair_ty") { if (value != 8 && value != 12) return fail(LBM_ERR_ARG, "pair_ty must be 8 or 12"); c->pair_ty = (int)value; }
@@ -1138,12 +1216,21 @@ const char* lbm_kernel_name(const lbm_ctx* c) {
     static thread_local char name[96];
     const char* t = c->p.precision == LBM_PRECISION_F32 ? "float" : "double";
     const char* nt = c->use_nt ? "true" : "false";
-    if (c->fuse > 1 && pair_possible(c)) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%s,%s>", c->fuse, t, c->pair_ty, c->pair_ty == 12 ? 768 : 512, nt, c->xcd ? "true" : "false");
+    if (c->fuse > 1 && c->slide) snprintf(name, sizeof(name), "k_step_slide<%s,%d,6,%s>", t, c->fuse, nt);
+    else if (c->fuse > 1 && pair_possible(c)) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%s,%s>", c->fuse, t, c->pair_ty, c->pair_ty == 12 ? 768 : 512, nt, c->xcd ? "true" : "false");
     else if (use_vec(c)) snprintf(name, sizeof(name), "k_step_vec<%s,%d,0,%s>", t, (int)(16 / c->esize), nt);
     else snprintf(name, sizeof(name), "k_step_site<%s,0,%s>", t, nt);
     return name;
 }
 
 const char* lbm_plan(const lbm_ctx* c) { return c ? c->plan_desc : ""; }
+
+#ifndef LBM_BUILD_ID_STR
+#define LBM_BUILD_ID_STR "unversioned-----"
+#endif
+const char* lbm_build_id(void) {
+    static const char tag[] = "LBM_BUILD_ID=" LBM_BUILD_ID_STR;   // the marker build.py looks for in the file
+    return tag + 13;
+}
 
 }  // extern "C"

@@ -130,10 +130,57 @@ __device__ __forceinline__ void apply_bcs(T (&f)[Q], bool bottom, bool top, bool
     }
 }
 
+// Arithmetic of the collision (the only place the two modes differ):
+//   AR_STRICT     the reference's expression tree evaluated operation by operation in IEEE arithmetic, no contraction,
+//                 two IEEE divisions: bit-identical to the strict CPU oracle (library default, parity tests).
+//   AR_CONTRACTED the same formulas as fused multiply-adds with ONE reciprocal of rho (two Newton steps on v_rcp): what the
+//                 reference's own build flags permit its compiler to do (CMakeLists.txt:21-22: -ffast-math -mfma). 70
+//                 instead of 150 floating-point instructions per cell; rho/u stay within 1e-10 of the reference (tests).
+enum Arith { AR_STRICT = 0, AR_CONTRACTED = 1 };
+
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double recip_t(double d) {      // 1/d to an ulp: v_rcp_f64 + two Newton steps
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma_t(fma_t(-d, r, 1.0), r, r);
+    r = fma_t(fma_t(-d, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ float recip_t(float d) {        // v_rcp_f32 (1 ulp) + one Newton step
+    float r = __builtin_amdgcn_rcpf(d);
+    return fma_t(fma_t(-d, r, 1.0f), r, r);
+}
+
 // collision_step for one cell, LBMSolver.h:101-123 (moments i = 0..8 ascending from 0, N7).
-template <typename T>
+template <typename T, int AR = AR_STRICT>
 __device__ __forceinline__ void bgk_collide(T (&f)[Q], T tau_inv) {
     T rho = T(0), ux = T(0), uy = T(0);
+    if (AR == AR_CONTRACTED) {
+        // moments as short trees over opposite pairs (depth 4 / 3 instead of chains of 9 / 6 dependent additions)
+        const T a13 = f[1] + f[3], a24 = f[2] + f[4], a57 = f[5] + f[7], a68 = f[6] + f[8];
+        const T d13 = f[1] - f[3], d24 = f[2] - f[4], d57 = f[5] - f[7], d68 = f[6] - f[8];
+        rho = ((f[0] + a13) + (a24 + a57)) + a68;
+        ux = (d13 + d57) - d68;
+        uy = (d24 + d57) + d68;
+        const T inv = recip_t(rho);
+        ux *= inv;
+        uy *= inv;
+        const T base = fma_t(T(-1.5), fma_t(ux, ux, uy * uy), T(1.0));      // 1 - 1.5 u^2
+        const T wr0 = wgt<T>(0) * rho, wr1 = wgt<T>(1) * rho, wr5 = wgt<T>(5) * rho;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            T cu;
+            if (cx(i) == 0 && cy(i) == 0) cu = T(0);
+            else if (cy(i) == 0) cu = T(cx(i)) * ux;
+            else if (cx(i) == 0) cu = T(cy(i)) * uy;
+            else cu = T(cx(i)) * ux + T(cy(i)) * uy;
+            // 1 + 3cu + 4.5cu^2 - 1.5u^2 = base + cu*(3 + 4.5cu);  f - (f - feq)/tau = f + (feq - f)/tau
+            const T t = (i == 0) ? base : fma_t(cu, fma_t(T(4.5), cu, T(3.0)), base);
+            const T wr = i == 0 ? wr0 : (i < 5 ? wr1 : wr5);
+            f[i] = fma_t(tau_inv, fma_t(wr, t, -f[i]), f[i]);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
         rho += f[i];
@@ -176,7 +223,7 @@ enum StepMode { MODE_STEP = 0, MODE_COLLIDE_ONLY = 1, MODE_STREAM_ONLY = 2 };
 //   MODE_COLLIDE_ONLY : collision_step of iteration 0 on the initial state (no pull, no BC, no stability test).
 //   MODE_STREAM_ONLY  : f_current snapshot for the accessor: pull + BCs + cylinder reversal
 //                       (LBMSolver.h:240-257), every interior cell written, no collision.
-template <typename T, int MODE, bool NT = false>
+template <typename T, int MODE, bool NT = false, int AR = AR_STRICT>
 __global__ void __launch_bounds__(256) k_step_site(const KArgs<T> a) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = row_of_block(a);
@@ -208,7 +255,7 @@ __global__ void __launch_bounds__(256) k_step_site(const KArgs<T> a) {
         }
     } else {
         if (solid) return;   // collision skips solid cells: they keep w_i for ever (LBMSolver.h:92, N4)
-        bgk_collide(f, a.tau_inv);
+        bgk_collide<T, AR>(f, a.tau_inv);
     }
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
@@ -224,7 +271,7 @@ __global__ void __launch_bounds__(256) k_step_site(const KArgs<T> a) {
 // (element-aligned dwordx4; the displaced wave touches 9 instead of 8 128-B lines, the extra one is shared with
 // its neighbour through L2). Requires nx % V == 0; other widths use k_step_site. Solid sites inside a vector are
 // rewritten with w_i, which is what they hold already (N4), so the stores stay full-width.
-template <typename T, int V, int MODE, bool NT = false>
+template <typename T, int V, int MODE, bool NT = false, int AR = AR_STRICT>
 __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
     typedef T VA __attribute__((ext_vector_type(V)));                       // naturally aligned vector
     typedef T VU __attribute__((ext_vector_type(V), aligned(sizeof(T))));   // element-aligned vector
@@ -271,7 +318,7 @@ __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
 #pragma unroll
             for (int i = 0; i < Q; ++i) f[i] = wgt<T>(i);
         } else {
-            bgk_collide(f, a.tau_inv);
+            bgk_collide<T, AR>(f, a.tau_inv);
         }
 #pragma unroll
         for (int i = 0; i < Q; ++i) fv[i][k] = f[i];
@@ -502,6 +549,181 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
         }
     }
     if (bad) atomicMin(a.unstable_t, a.t + 2);
+}
+
+// D iterations per launch with a SLIDING WINDOW in y (temporal blocking without y-overlap). A block owns a column of
+// TX = 64 cells and a segment of rows [S0, S1); it marches up the segment in bands of B rows. At band k, level l
+// (l = 1..D; level l holds P_{t+l}) computes the B rows starting at S0 + k*B + (D-l): level 1 leads, level D (the
+// rows stored to HBM) trails by D-1 rows. Level l+1 pulls from an LDS ring of level l that keeps B+2 rows: the band
+// just produced plus the last two rows of the previous band. Per (plane, row, column) a pull scheme reads every value
+// exactly once, so nothing is re-read in y; only the x-halo (D-1 columns per side at level 1, shrinking by one per
+// level) is recomputed, plus D-1, D-2, .. rows once per segment as warm-up. Against k_step3_tile (64x12 tile: 1.42x
+// cell reads, 1.21x collisions) a 64-wide column with 128-row segments reads 1.08x and computes 1.05x.
+//   waves 0..B-1 : "row waves", one row of the band each, lane = x (coalesced 512-B global rows, conflict-free LDS)
+//   wave  B      : "halo wave", the 2*(D-l) halo cells of each of the B rows at level l (idle at level D)
+// The level-1 inputs of band k+1 are loaded from HBM into registers BEFORE the levels 2..D of band k are computed
+// (software prefetch: the loads overlap the arithmetic inside a block); D-1 barriers per band. The block -> (column,
+// segment) map gives every XCD one run of x-adjacent columns at the same height, so the cache lines two columns share
+// at their common edge meet in the same L2. Same per-cell operation sequence as every other step kernel =>
+// bit-identical results (tests). LDS: (D-1)*(B+2)*9*(64+2(D-1))*sizeof(T) = 78,336 B at D=3, B=6, fp64: two blocks
+// per CU. The host sizes the segments so that all blocks are resident at once (no tail wave).
+struct SlideArgs { int seg_h, nseg1, nseg2, ncol; };
+
+template <typename T, int D, int B, bool NT, int AR = AR_STRICT>
+__global__ void __launch_bounds__((B + 1) * 64, 4) k_step_slide(const KArgs<T> a, const K2Extra<T> e, const SlideArgs s) {
+    constexpr int TX = 64, HW = D - 1, LW = TX + 2 * HW, NS = B + 2;
+    static_assert(D >= 2 && D <= 4 && 2 * HW * B <= 64, "the halo wave covers 2*(D-1) cells of each of the B rows");
+    __shared__ T ring[D - 1][NS][Q][LW];
+    __shared__ T s_feq[Q];      // permanent content of physical N/S ghost rows; in LDS so that the loop holds no vector-memory
+                                // load besides the prefetch (a global load here would drain the prefetch at its s_waitcnt)
+    if (threadIdx.x < Q) s_feq[threadIdx.x] = e.feq_in[threadIdx.x];
+    int b = blockIdx.x;
+    {
+        const int nb = gridDim.x;
+        if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;       // XCD j walks the j-th contiguous run of blocks
+    }
+    const int seg = b / s.ncol, col = b - seg * s.ncol;
+    int S0, S1;
+    if (seg < s.nseg1) { S0 = a.y_lo + seg * s.seg_h; S1 = min(S0 + s.seg_h, a.y_lo + a.y_cnt); }
+    else { S0 = a.y_lo2 + (seg - s.nseg1) * s.seg_h; S1 = min(S0 + s.seg_h, a.y_lo2 + a.y_cnt2); }
+    const int X0 = col * TX;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool halo_wave = (w == B);
+    const int K = (S1 - S0 + B - 1) / B;                        // bands 0..K-1; band -1 is the warm-up
+
+    // this thread's cell at level l of band kb (level-l rows of band kb start at S0 + kb*B + (D-l)); false: no cell here
+    auto cell_xy = [&](int l, int kb, int& x, int& y) -> bool {
+        const int hw = D - l, R = S0 + kb * B + hw;
+        if (!halo_wave) { x = X0 + lane; y = R + w; return true; }
+        if (hw == 0) return false;
+        const int r = lane / (2 * hw), h = lane - r * (2 * hw);
+        x = (h < hw) ? X0 - hw + h : X0 + TX + (h - hw);
+        y = R + r;
+        return r < B;
+    };
+    // ... and is it a row some output of this segment depends on?
+    auto cell = [&](int l, int kb, int& x, int& y) -> bool {
+        return cell_xy(l, kb, x, y) && y >= S0 - (D - l) && y < S1 + (D - l);
+    };
+    auto slot_of = [&](int y) -> int { return (y - S0 + 2 * NS) % NS; };
+    // byte-free LDS element index of ring `r`, row slot `sl`, plane i, column xx (24-bit multiply: one full-rate instruction)
+    auto ring_at = [&](int r, int sl, int i, int xx) -> T& { return (&ring[0][0][0][0])[__mul24(r * NS + sl, Q * LW) + i * LW + xx]; };
+
+    // Addressing: one uniform base per buffer + a 32-bit byte offset per access (the host launches this kernel only for
+    // buffers below 4 GiB), so that the nine plane addresses cost one vector add each instead of a hoisted 64-bit
+    // scalar pair per plane and buffer (the kernel is scalar-register bound).
+    const char* const sbase = reinterpret_cast<const char*>(a.src);
+    char* const dbase = reinterpret_cast<char*>(a.dst);
+    const unsigned pitchB = (unsigned)a.pitch * (unsigned)sizeof(T), planeB = (unsigned)a.plane * (unsigned)sizeof(T);
+    auto cell_off = [&](int x, int y) -> unsigned { return (unsigned)(y + GR) * pitchB + (unsigned)(a.xoff + x) * (unsigned)sizeof(T); };
+
+    // raw pulled populations of this thread's level-1 cell of band kb (left untouched where the cell is not computed)
+    auto fetch = [&](int kb, T (&v)[Q]) {
+        int x, y;
+        if (kb >= K || !cell(1, kb, x, y)) return;
+        const int yg = a.y_start + y;
+        if (yg < 0 || yg >= a.ny_glob || x < 0 || x >= a.nx) return;
+        const unsigned c = cell_off(x, y);
+#pragma unroll
+        for (int i = 0; i < Q; ++i)
+            v[i] = *reinterpret_cast<const T*>(sbase + (c + (unsigned)i * planeB - (unsigned)cy(i) * pitchB - (unsigned)(cx(i) * (int)sizeof(T))));
+    };
+
+    bool bad[D];
+#pragma unroll
+    for (int l = 0; l < D; ++l) bad[l] = false;
+    bool near_cyl = false;
+
+    // One cell of level L (1..D) of band kb: f = the pulled populations for L == 1, else pulled from the ring of L-1.
+    // LEAN (block-uniform, decided per iteration): every cell of the iteration is a fluid cell strictly inside the
+    // domain on a row that is needed — no boundary, solid, ghost or validity logic at all.
+    auto level = [&]<int L, bool LEAN>(int kb, T (&f)[Q]) {
+        int x, y;
+        if (LEAN ? !cell_xy(L, kb, x, y) : !cell(L, kb, x, y)) return;
+        const int yg = a.y_start + y;
+        const int xx = x - X0 + HW;
+        bool store = true;
+        bool inside = true;
+        if (!LEAN) {
+            const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+            inside = row_in && col_in;
+            if (!inside) {
+                if (L == D) return;
+#pragma unroll
+                for (int i = 0; i < Q; ++i) f[i] = (row_in && !col_in) ? T(0) : s_feq[i];
+            }
+        }
+        if (inside) {
+            if (L > 1) {
+                int sl[3];                                      // slots of rows y-1, y, y+1
+#pragma unroll
+                for (int d = 0; d < 3; ++d) sl[d] = (y + d - 1 - S0 + 2 * NS) % NS;
+#pragma unroll
+                for (int i = 0; i < Q; ++i) f[i] = ring_at(L > 1 ? L - 2 : 0, sl[1 - cy(i)], i, xx - cx(i));
+            }
+            if (!LEAN) {
+                bool solid = false;
+                if (near_cyl) solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);   // block-uniform branch
+                T rho_bc, u_out;
+                if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+                bad[L - 1] |= any_unstable(f);
+                bgk_collide<T, AR>(f, a.tau_inv);
+                if (near_cyl) {                    // solid cells keep w_i (the collision result of such a cell is discarded)
+                    if (L == D) store = !solid;
+                    else {
+#pragma unroll
+                        for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
+                    }
+                }
+            } else {
+                bad[L - 1] |= any_unstable(f);
+                bgk_collide<T, AR>(f, a.tau_inv);
+            }
+        }
+        if (L < D) {
+            const int sl = slot_of(y);
+#pragma unroll
+            for (int i = 0; i < Q; ++i) ring_at(L < D ? L - 1 : 0, sl, i, xx) = f[i];
+        } else if (store) {
+            const unsigned c = cell_off(x, y);
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                T* p = reinterpret_cast<T*>(dbase + (c + (unsigned)i * planeB));
+                if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
+            }
+        }
+    };
+
+    T nxt[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) nxt[i] = T(0);
+    fetch(-1, nxt);
+    __syncthreads();                                            // s_feq
+    // Iteration k: level 1 of band k (consumes the prefetched registers: the only point that waits for vector memory,
+    // and everything outstanding there — the loads of band k and the stores of band k-2 — was issued at least a third
+    // of an iteration earlier), prefetch of band k+1, level D of band k-1 (stores), then levels 2..D-1 of band k.
+    // ring[l-1] is written by level l between two barriers and read by level l+1 after the second one.
+    auto iteration = [&]<bool LEAN>(int k) {
+        T f[Q];
+        if (D == 2) {                                           // one ring: level 2 must have read it before level 1 rewrites it
+            level.template operator()<D, LEAN>(k - 1, f);
+            __syncthreads();
+        }
+        level.template operator()<1, LEAN>(k, nxt);
+        fetch(k + 1, nxt);
+        if (D > 2) level.template operator()<D, LEAN>(k - 1, f);
+        __syncthreads();
+        if constexpr (D >= 3) { level.template operator()<2, LEAN>(k, f); __syncthreads(); }
+        if constexpr (D >= 4) { level.template operator()<3, LEAN>(k, f); __syncthreads(); }
+    };
+    for (int k = -1; k <= K; ++k) {
+        // block-uniform: can any cell this iteration touches (all levels, halo included) be solid?
+        near_cyl = tile_near_cylinder(a, X0, S0 + (k - 1) * B, TX, 2 * B + HW, HW);
+        iteration.template operator()<false>(k);
+    }
+#pragma unroll
+    for (int l = 0; l < D; ++l)
+        if (bad[l]) atomicMin(a.unstable_t, a.t + l);
 }
 
 // ---------------------------------------------------------------------------------------------------------

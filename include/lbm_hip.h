@@ -149,6 +149,9 @@ int  lbm_last_step_stats(lbm_ctx* c, double* ms_total, int* launches, int* itera
 const char* lbm_kernel_name(const lbm_ctx* c);
 /* The plan lbm_initialise settled on (layout / kernel / store policy / traversal), for logs. */
 const char* lbm_plan(const lbm_ctx* c);
+/* SHA-256 (16 hex digits) of the sources this binary was compiled from (csrc/ and this header); build.py rebuilds
+ * when it differs from the tree, bench.py prints it. */
+const char* lbm_build_id(void);
 
 #ifdef __cplusplus
 }
