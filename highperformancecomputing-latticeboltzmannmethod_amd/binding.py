@@ -58,6 +58,11 @@ def lib():
         L.lbm_comm_unique_id.argtypes = [vp]
         L.lbm_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
         L.lbm_comm_allreduce.argtypes = [vp, dp, C.c_int, C.c_int]
+        pp = C.POINTER(vp)
+        L.lbm_group_link.argtypes = [pp, C.c_int, C.c_int]
+        L.lbm_group_initialise.argtypes = [pp, C.c_int, C.POINTER(C.c_int)]
+        L.lbm_group_step.argtypes = [pp, C.c_int, C.c_int, C.c_int]
+        L.lbm_group_refresh_halos.argtypes = [pp, C.c_int]
         L.lbm_halo_export.argtypes = [vp, dp, dp]
         L.lbm_halo_import.argtypes = [vp, dp, dp]
         L.lbm_set_option.argtypes = [vp, C.c_char_p, C.c_long]
@@ -232,3 +237,85 @@ class Context:
 
     def plan(self):
         return self.L.lbm_plan(self.h).decode()
+
+
+class Group:
+    """n strips of one lattice driven in lockstep by this process (lbm_group_*): one Context per strip, bottom to top.
+    transport: "peer" (device copies / hipMemcpyPeerAsync) or "rccl" (ncclCommInitAll; distinct devices)."""
+
+    def __init__(self, nx, ny, bounds, devices=None, transport="peer", options=None, **kw):
+        from .strips import partition_rows
+        if isinstance(bounds, int):
+            bounds = partition_rows(ny, bounds)
+        devices = devices or [0] * len(bounds)
+        self.nx, self.ny = nx, ny
+        self.ctxs = [Context(nx, ny, y_start=y0, local_ny=n, device=d, options=options, **kw)
+                     for (y0, n), d in zip(bounds, devices)]
+        self.L = lib()
+        self._arr = (C.c_void_p * len(self.ctxs))(*[c.h for c in self.ctxs])
+        self._n = len(self.ctxs)
+        self._chk(self.L.lbm_group_link(self._arr, self._n, {"peer": 0, "rccl": 1}[transport]))
+        self.solid_count = None
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise LbmError(f"lbm_hip error {rc}: {self.L.lbm_last_error().decode()}")
+        return rc
+
+    def initialise(self):
+        n = C.c_int()
+        self._chk(self.L.lbm_group_initialise(self._arr, self._n, C.byref(n)))
+        self.solid_count = n.value
+        return n.value
+
+    def step(self, nsteps=1, output_frequency=0):
+        self._chk(self.L.lbm_group_step(self._arr, self._n, nsteps, output_frequency))
+
+    def refresh_halos(self):
+        self._chk(self.L.lbm_group_refresh_halos(self._arr, self._n))
+
+    def sync(self):
+        for c in self.ctxs:
+            c.sync()
+
+    @property
+    def steps_done(self):
+        return self.ctxs[0].steps_done
+
+    def first_unstable_step(self):
+        """min over the strips (the reference's MPI_Allreduce(MIN) of the stability flag, LBMGrid.h:315)."""
+        bad = [t for t in (c.first_unstable_step() for c in self.ctxs) if t >= 0]
+        return min(bad) if bad else -1
+
+    def macros(self):
+        """(rho, ux, uy) of the whole lattice: the strips' rows concatenated by y_start (LBMSolver.h:340-357)."""
+        parts = [c.macros() for c in self.ctxs]
+        return tuple(np.concatenate([p[j] for p in parts], axis=0) for j in range(3))
+
+    def populations(self, which):
+        """Ghost-inclusive [(ny+2), (nx+2), 9]: interior rows of every strip + the physical ghost rows of the end strips."""
+        parts = [c.populations(which) for c in self.ctxs]
+        rows = [parts[0][:1]] + [p[1:-1] for p in parts] + [parts[-1][-1:]]
+        return np.concatenate(rows, axis=0)
+
+    def drain_force_log(self):
+        """Rows summed over the strips (the reference's MPI_Reduce(SUM), LBMIO.h:167-168)."""
+        logs = [c.drain_force_log() for c in self.ctxs]
+        return [(logs[0][k][0], sum(l[k][1] for l in logs), sum(l[k][2] for l in logs)) for k in range(len(logs[0]))]
+
+    def forces(self):
+        f = [c.forces() for c in self.ctxs]
+        return sum(v[0] for v in f), sum(v[1] for v in f)
+
+    def max_velocity_sq(self):
+        return max(c.max_velocity_sq() for c in self.ctxs)
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -103,6 +103,12 @@ struct lbm_ctx {
     int rank = 0, nranks = 1;
     bool comm_issued = false;   // ev_comm has been recorded at least once
     double* d_red = nullptr;
+    // in-process group of strips (lbm_group_link): neighbours, transport (0 peer copies, 1 RCCL), size
+    lbm_ctx* nb_south = nullptr;
+    lbm_ctx* nb_north = nullptr;
+    int group_transport = 0, group_n = 1, group_k = 0;
+    bool owns_comm = true;
+    int edge_rows[2] = {0, 0};   // edge-band heights of the launch in flight (issue_before -> issue_after)
     // host-staged halo staging (device side)
     double* d_halo = nullptr;  // 4 faces-in-flight x [GR][9][nx] doubles
 };
@@ -289,152 +295,165 @@ int launch_forces(lbm_ctx* c, double* out, int t) {
     return LBM_OK;
 }
 
-// ---- halo exchange over RCCL -------------------------------------------------------------------------
+// ---- strip halo exchange ----------------------------------------------------------------------------------
 // After a launch has produced the new populations in buf[dst]: my top GR interior rows go to the north neighbour's
 // south ghost rows, my bottom GR interior rows to the south neighbour's north ghost rows, all nine populations
 // (a fused launch recomputes up to two of the neighbour's rows, which needs every population; per lattice update
 // this is the reference's 9 values per edge cell, LBMGrid.h:404-406). Strips always use the row-interleaved layout, in
-// which GR rows x 9 sub-rows are ONE contiguous run of GR*pitch elements: one send + one recv per face, no packing.
+// which GR rows x 9 sub-rows are ONE contiguous run of GR*pitch elements: one message per face, no packing.
+// FaceSpans is the single place the offsets and the count are computed; every transport below uses it.
+struct FaceSpans {
+    size_t cnt;       // elements per face message (GR rows x pitch)
+    long top_rows;    // my top GR interior rows      (gy = nyl .. nyl+GR-1)    -> north neighbour's ghost_s
+    long bot_rows;    // my bottom GR interior rows   (gy = GR .. 2GR-1)        -> south neighbour's ghost_n
+    long ghost_n;     // my north ghost rows          (gy = nyl+GR .. nyl+2GR-1)
+    long ghost_s;     // my south ghost rows          (gy = 0 .. GR-1)
+};
+inline FaceSpans face_spans(const lbm_ctx* c) {
+    FaceSpans f;
+    f.cnt = (size_t)GR * c->pitch;
+    f.top_rows = (long)c->nyl * c->pitch;
+    f.bot_rows = (long)GR * c->pitch;
+    f.ghost_n = (long)(c->nyl + GR) * c->pitch;
+    f.ghost_s = 0;
+    return f;
+}
+
+// Transports of ONE context: RCCL send/recv between processes (rank r <-> r-1, r+1), or the test-only loopbacks.
 template <typename T>
 int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
+    const FaceSpans f = face_spans(c);
+    T* b = static_cast<T*>(c->buf[dst]);
+    const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
     if (c->loopback) {   // test transports: my own edge rows become my ghost rows
-        T* b = static_cast<T*>(c->buf[dst]);
         if (c->layout != 1) return fail(LBM_ERR_COMM, "loopback requires the row-interleaved layout");
         if (c->loopback == 2) {   // ... through RCCL itself: a one-rank communicator sending to / receiving from rank 0
             if (!c->comm) return fail(LBM_ERR_COMM, "loopback=2 needs lbm_comm_init(c, 0, 1, id)");
-            const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
-            const size_t cnt = (size_t)GR * c->pitch;
             NCCLCHK(ncclGroupStart());        // self send/recv pairs match in posting order
-            NCCLCHK(ncclSend(b + (long)c->nyl * c->pitch, cnt, dt, 0, c->comm, s));          // top rows ...
-            NCCLCHK(ncclRecv(b, cnt, dt, 0, c->comm, s));                                    // ... -> south ghost rows
-            NCCLCHK(ncclSend(b + (long)GR * c->pitch, cnt, dt, 0, c->comm, s));              // bottom rows ...
-            NCCLCHK(ncclRecv(b + (long)(c->nyl + GR) * c->pitch, cnt, dt, 0, c->comm, s));   // ... -> north ghost rows
+            NCCLCHK(ncclSend(b + f.top_rows, f.cnt, dt, 0, c->comm, s));
+            NCCLCHK(ncclRecv(b + f.ghost_s, f.cnt, dt, 0, c->comm, s));
+            NCCLCHK(ncclSend(b + f.bot_rows, f.cnt, dt, 0, c->comm, s));
+            NCCLCHK(ncclRecv(b + f.ghost_n, f.cnt, dt, 0, c->comm, s));
             NCCLCHK(ncclGroupEnd());
             return LBM_OK;
         }
-        const size_t bytes = (size_t)GR * c->pitch * sizeof(T);   // ... or plain device copies on the same stream
-        HIPCHK(hipMemcpyAsync(b, b + (long)c->nyl * c->pitch, bytes, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(b + (long)(c->nyl + GR) * c->pitch, b + (long)GR * c->pitch, bytes, hipMemcpyDeviceToDevice, s));
+        const size_t bytes = f.cnt * sizeof(T);                   // ... or plain device copies on the same stream
+        HIPCHK(hipMemcpyAsync(b + f.ghost_s, b + f.top_rows, bytes, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(b + f.ghost_n, b + f.bot_rows, bytes, hipMemcpyDeviceToDevice, s));
         return LBM_OK;
     }
     if (c->nranks <= 1) return LBM_OK;
     if (c->layout != 1) return fail(LBM_ERR_COMM, "strips require the row-interleaved layout");
-    T* base = static_cast<T*>(c->buf[dst]);
-    const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
-    const size_t cnt = (size_t)GR * c->pitch;
-    const long top_rows = (long)c->nyl * c->pitch;            // gy = nyl .. nyl+GR-1   (interior rows nyl-GR .. nyl-1)
-    const long bot_rows = (long)GR * c->pitch;                // gy = GR .. 2GR-1        (interior rows 0 .. GR-1)
-    const long ghost_n = (long)(c->nyl + GR) * c->pitch;      // north ghost rows
-    const long ghost_s = 0;                                   // south ghost rows
     NCCLCHK(ncclGroupStart());
     if (c->rank + 1 < c->nranks) {
-        NCCLCHK(ncclSend(base + top_rows, cnt, dt, c->rank + 1, c->comm, s));
-        NCCLCHK(ncclRecv(base + ghost_n, cnt, dt, c->rank + 1, c->comm, s));
+        NCCLCHK(ncclSend(b + f.top_rows, f.cnt, dt, c->rank + 1, c->comm, s));
+        NCCLCHK(ncclRecv(b + f.ghost_n, f.cnt, dt, c->rank + 1, c->comm, s));
     }
     if (c->rank > 0) {
-        NCCLCHK(ncclSend(base + bot_rows, cnt, dt, c->rank - 1, c->comm, s));
-        NCCLCHK(ncclRecv(base + ghost_s, cnt, dt, c->rank - 1, c->comm, s));
+        NCCLCHK(ncclSend(b + f.bot_rows, f.cnt, dt, c->rank - 1, c->comm, s));
+        NCCLCHK(ncclRecv(b + f.ghost_s, f.cnt, dt, c->rank - 1, c->comm, s));
     }
     NCCLCHK(ncclGroupEnd());
     return LBM_OK;
 }
 
-// One launch group (one iteration, or two/three with a fused kernel) of a strip that has neighbours.
-// The E rows next to each neighbour ("edge bands": E = GR for one iteration, one tile band when fused) contain the GR
-// rows that are sent. They are updated by ONE launch on the side stream, followed there by the RCCL group; the
-// remaining interior rows are updated concurrently on the main stream:
+inline hipStream_t exchange_stream(const lbm_ctx* c) { return c->overlap ? c->comm_stream : c->stream; }
+
+// Transports of an in-process GROUP of strips (lbm_group_link): every member's exchange is issued by the one host
+// thread that drives the group, after every member's edge rows have been queued.
+//   peer : each strip PULLS its neighbours' edge rows into its own ghost rows (hipMemcpyPeerAsync over xGMI, a plain
+//          device copy when both strips share a device) on its own exchange stream, behind the neighbour's ev_edge;
+//   rccl : all members' ncclSend/ncclRecv inside ONE ncclGroupStart/End (one communicator per member, ncclCommInitAll).
+template <typename T>
+int exchange_group(lbm_ctx** cs, int n, int dst) {
+    if (n < 2) return LBM_OK;
+    if (cs[0]->group_transport == 1) {
+        const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+        NCCLCHK(ncclGroupStart());
+        for (int k = 0; k < n; ++k) {
+            lbm_ctx* c = cs[k];
+            const FaceSpans f = face_spans(c);
+            T* b = static_cast<T*>(c->buf[dst]);
+            hipStream_t s = exchange_stream(c);
+            if (k + 1 < n) {
+                NCCLCHK(ncclSend(b + f.top_rows, f.cnt, dt, k + 1, c->comm, s));
+                NCCLCHK(ncclRecv(b + f.ghost_n, f.cnt, dt, k + 1, c->comm, s));
+            }
+            if (k > 0) {
+                NCCLCHK(ncclSend(b + f.bot_rows, f.cnt, dt, k - 1, c->comm, s));
+                NCCLCHK(ncclRecv(b + f.ghost_s, f.cnt, dt, k - 1, c->comm, s));
+            }
+        }
+        NCCLCHK(ncclGroupEnd());
+        return LBM_OK;
+    }
+    for (int k = 0; k < n; ++k) {
+        lbm_ctx* c = cs[k];
+        HIPCHK(hipSetDevice(c->device));
+        const FaceSpans f = face_spans(c);
+        T* b = static_cast<T*>(c->buf[dst]);
+        hipStream_t s = exchange_stream(c);
+        const size_t bytes = f.cnt * sizeof(T);
+        auto pull = [&](lbm_ctx* nb, long nb_rows, long my_ghost) -> int {
+            const T* src = static_cast<const T*>(nb->buf[dst]) + nb_rows;
+            HIPCHK(hipStreamWaitEvent(s, nb->ev_edge, 0));            // the neighbour's edge rows of this launch are written
+            if (nb->device == c->device) HIPCHK(hipMemcpyAsync(b + my_ghost, src, bytes, hipMemcpyDeviceToDevice, s));
+            else HIPCHK(hipMemcpyPeerAsync(b + my_ghost, c->device, src, nb->device, bytes, s));
+            return LBM_OK;
+        };
+        if (k > 0) { int rc = pull(cs[k - 1], face_spans(cs[k - 1]).top_rows, f.ghost_s); if (rc) return rc; }
+        if (k + 1 < n) { int rc = pull(cs[k + 1], face_spans(cs[k + 1]).bot_rows, f.ghost_n); if (rc) return rc; }
+    }
+    return LBM_OK;
+}
+
+// ---- one launch, in phases --------------------------------------------------------------------------------
+// A launch advances `depth` iterations (1, or 2/3 fused). Strips (a context with internal faces) issue launches in
+// pairs between halo exchanges: KIND_EXTENDED (first of a pair: the strip's rows plus EXT ghost rows per internal
+// face, no exchange afterwards) and KIND_EXCHANGE (a normal launch followed by the exchange of GR rows); without
+// deep halos every launch is KIND_EXCHANGE. KIND_LOCAL: no neighbour to talk to.
+//
+// KIND_EXCHANGE with overlap. The E rows next to each neighbour ("edge bands": E = GR for one iteration,
+// one band of the fused kernel otherwise) contain the GR rows that travel. They are updated by ONE launch on the side
+// stream, followed there by the exchange; the remaining interior rows are updated concurrently on the main stream:
 //   side stream : wait(ev_main: everything queued on the main stream so far) -> edge bands -> record(ev_edge)
-//                 -> ncclSend/ncclRecv group -> record(ev_comm)
+//                 -> exchange -> record(ev_comm)
 //   main stream : record(ev_main) ... wait(ev_edge of the PREVIOUS group) -> interior rows
 // Hazards: edge(n) and interior(n) both read rows the other kind wrote in group n-1 (ev_main / ev_edge); edge(n) reads
 // the ghost rows recv(n-1) wrote and recv(n) overwrites ghost rows edge(n-1) read, send(n) reads what edge(n) wrote,
 // edge(n+1) overwrites rows send(n-1) read (all ordered by the side stream itself); interior(n) overwrites rows of
 // the buffer edge(n-1) read (ev_edge). Interior rows read no ghost row (E >= GR) and write no edge row. Consumers on
-// the main stream (forces, snapshots) first wait for ev_comm (join_comm).
-template <typename T>
-int advance_with_exchange(lbm_ctx* c, int src, int dst, int t, int depth) {
-    KArgs<T> a = make_kargs<T>(c, src, dst, t);
-    const bool has_s = c->rank > 0 || c->loopback, has_n = c->rank + 1 < c->nranks || c->loopback;
-    auto launch = [&](hipStream_t s) {
-        if (depth > 1) launch_fused_rows<T>(c, a, depth, s);
-        else launch_rows<T, MODE_STEP>(c, a, s);
-    };
-    const int rev = (c->alternate && (c->launches_total & 1)) ? 1 : 0;
-    if (!c->overlap) {
-        a.reverse = rev;
-        launch(c->stream);
-        HIPCHK(hipGetLastError());
-        return exchange_rccl<T>(c, dst, c->stream);
-    }
-    const int E = depth > 1 ? (c->slide ? GR : c->pair_ty) : GR;   // one tile band / one band of the sliding kernel
-    int e0 = has_s ? E : 0, e1 = has_n ? E : 0;
-    if (e0 + e1 >= c->nyl) { e0 = c->nyl; e1 = 0; }          // short strip: everything is edge
-    HIPCHK(hipEventRecord(c->ev_main, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_main, 0));
-    if (c->comm_issued) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_edge, 0));   // ev_edge still is the previous group's
-    a.reverse = 0;
-    a.y_lo = 0; a.y_cnt = e0; a.y_lo2 = c->nyl - e1; a.y_cnt2 = e1;
-    if (e0 == 0) { a.y_lo = a.y_lo2; a.y_cnt = e1; a.y_cnt2 = 0; }
-    launch(c->comm_stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev_edge, c->comm_stream));
-    int rc = exchange_rccl<T>(c, dst, c->comm_stream);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
-    c->comm_issued = true;
-    if (c->nyl - e0 - e1 > 0) {
-        a.y_lo = e0; a.y_cnt = c->nyl - e0 - e1; a.y_lo2 = 0; a.y_cnt2 = 0; a.reverse = rev;
-        launch(c->stream);
-        HIPCHK(hipGetLastError());
-    }
-    return LBM_OK;
-}
+// the main stream (forces, snapshots) first wait for ev_comm (join_comm). In a group with the peer transport a strip's
+// edge rows are additionally read by its NEIGHBOURS' pulls: before they are overwritten the launching stream waits for
+// the neighbours' ev_comm (their last pull).
+// Without overlap the whole launch and the exchange run on the main stream (ev_edge / ev_comm are recorded all the
+// same: the group transports order themselves by them).
+enum { KIND_LOCAL = 0, KIND_EXTENDED = 1, KIND_EXCHANGE = 2 };
+struct Launch { int depth, kind, src, dst, t; };
 
 inline int join_comm(lbm_ctx* c);
-
-// One launch without neighbours.
-template <typename T>
-int advance_local(lbm_ctx* c, int src, int dst, int t, int depth) {
-    return launch_step<T>(c, src, dst, t, depth > 1 ? 100 + depth : MODE_STEP, c->stream);
-}
-
-// EXT rows of each internal face are recomputed by the first launch of a pair (see advance).
-constexpr int EXT = 3;
+constexpr int EXT = 3;   // rows of each internal face recomputed by the first launch of a pair
 inline bool face_south(const lbm_ctx* c) { return c->p.y_start > 0 || c->loopback; }
 inline bool face_north(const lbm_ctx* c) { return c->p.y_start + c->nyl < c->p.ny || c->loopback; }
 
-// First launch of a pair: all rows of the strip PLUS the EXT ghost rows next to each internal face, one launch on the
-// main stream, no exchange afterwards. The ghost rows it reads (up to 2*EXT = GR deep) came with the last exchange.
 template <typename T>
-int advance_extended(lbm_ctx* c, int src, int dst, int t, int depth) {
-    int rc = join_comm(c);          // the last exchange (and the edge bands before it) live on the side stream
-    if (rc) return rc;
-    KArgs<T> a = make_kargs<T>(c, src, dst, t);
-    const int es = face_south(c) ? EXT : 0, en = face_north(c) ? EXT : 0;
-    a.y_lo = -es;
-    a.y_cnt = c->nyl + es + en;
-    a.reverse = (c->alternate && (c->launches_total & 1)) ? 1 : 0;
-    if (depth > 1) launch_fused_rows<T>(c, a, depth, c->stream);
-    else launch_rows<T, MODE_STEP>(c, a, c->stream);
-    HIPCHK(hipGetLastError());
-    return LBM_OK;
+void launch_depth(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s) {
+    if (depth > 1) launch_fused_rows<T>(c, a, depth, s);
+    else launch_rows<T, MODE_STEP>(c, a, s);
 }
 
-// Advance by up to `remaining` iterations with ONE launch; returns the number of iterations taken (1..3) or <0.
-// Fusion: d iterations are fused only when the plan allows it, when none of the iterations t+1 .. t+d-1 is a
-// force-output iteration (their post-collision states never exist in memory) and when at least one more iteration
-// follows inside this call, so that the last launch of every lbm_step call is a single iteration and buf[cur^1] holds
-// the previous iteration's populations (macro snapshot / f_current accessors).
-// Strips: launches come in pairs between halo exchanges. The first launch of a pair is "extended" (advance_extended,
-// no exchange after it), the second is a normal launch followed by the exchange of GR rows; the last launch of a
-// call is never a first one, so every call ends with valid ghost rows. Every rank derives the same sequence from
-// (steps_done, remaining, output_frequency). Without a device transport (host-staged halos: the caller exchanges
-// after every call) a call may therefore contain at most two launches.
-template <typename T>
-int advance(lbm_ctx* c, int remaining, int of, bool transport, bool strip_logic = true) {
+// Decide the next launch of a context that still has `remaining` iterations to go in this call. Fusion: d iterations are
+// fused only when the plan allows it, when none of the iterations t+1 .. t+d-1 is a force-output iteration (their
+// post-collision states never exist in memory) and when at least one more iteration follows inside this call, so that
+// the last launch of every lbm_step call is a single iteration and buf[cur^1] holds the previous iteration's
+// populations (macro snapshot / f_current accessors) — unless "trailing_pair" lifts that rule. The last launch of a call
+// is never the first of a pair, so every call ends with valid ghost rows. Every rank derives the same sequence from
+// (steps_done, remaining, output_frequency). Without a device transport (host-staged halos: the caller exchanges after
+// every call) a call may therefore contain at most two launches.
+inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool strip_logic, Launch* L) {
     const int t = c->steps_done;
     int depth = 1;
-    if (c->fuse > 1 && pair_possible(c)) {
+    if (c->fuse > 1) {
         for (int d = std::min(c->fuse, 3); d >= 2 && depth == 1; --d) {
             if (remaining < d + (c->trailing_pair ? 0 : 1)) continue;
             bool ok = true;
@@ -444,25 +463,114 @@ int advance(lbm_ctx* c, int remaining, int of, bool transport, bool strip_logic 
     }
     const bool faces = strip_logic && (face_south(c) || face_north(c));
     const bool last = remaining - depth <= 0;
-    const int src = c->cur, dst = c->cur ^ 1;
-    int rc;
-    if (faces && c->deep_halo && !last && !c->mid_pair) {
-        rc = advance_extended<T>(c, src, dst, t, depth);
-        c->mid_pair = true;
-    } else {
+    L->depth = depth; L->src = c->cur; L->dst = c->cur ^ 1; L->t = t;
+    if (faces && c->deep_halo && !last && !c->mid_pair) L->kind = KIND_EXTENDED;
+    else {
         if (faces && !transport && !last)
             return fail(LBM_ERR_ARG, "a strip with host-staged halos can take at most two launches per lbm_step call "
                                      "(exchange the edge rows, then call again)");
-        rc = transport ? advance_with_exchange<T>(c, src, dst, t, depth) : advance_local<T>(c, src, dst, t, depth);
-        c->mid_pair = false;
+        L->kind = transport ? KIND_EXCHANGE : KIND_LOCAL;
     }
+    return LBM_OK;
+}
+
+// Everything of a launch that precedes its exchange.
+template <typename T>
+int issue_before(lbm_ctx* c, const Launch& L) {
+    KArgs<T> a = make_kargs<T>(c, L.src, L.dst, L.t);
+    const int rev = (c->alternate && (c->launches_total & 1)) ? 1 : 0;
+    if (L.kind == KIND_LOCAL) {
+        a.reverse = rev;
+        launch_depth<T>(c, a, L.depth, c->stream);
+        HIPCHK(hipGetLastError());
+        return LBM_OK;
+    }
+    if (L.kind == KIND_EXTENDED) {   // all rows of the strip PLUS the EXT ghost rows next to each internal face, main stream
+        int rc = join_comm(c);       // the last exchange (and the edge bands before it) live on the side stream
+        if (rc) return rc;
+        const int es = face_south(c) ? EXT : 0, en = face_north(c) ? EXT : 0;
+        a.y_lo = -es;
+        a.y_cnt = c->nyl + es + en;
+        a.reverse = rev;
+        launch_depth<T>(c, a, L.depth, c->stream);
+        HIPCHK(hipGetLastError());
+        return LBM_OK;
+    }
+    hipStream_t es = exchange_stream(c);
+    auto wait_for_neighbour_pulls = [&]() -> int {   // group / peer: my edge rows of buf[dst] may still be being read
+        for (lbm_ctx* nb : {c->nb_south, c->nb_north})
+            if (nb && c->group_transport == 0 && nb->comm_issued) HIPCHK(hipStreamWaitEvent(es, nb->ev_comm, 0));
+        return LBM_OK;
+    };
+    if (!c->overlap) {
+        int rc = wait_for_neighbour_pulls();
+        if (rc) return rc;
+        a.reverse = rev;
+        launch_depth<T>(c, a, L.depth, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev_edge, c->stream));
+        return LBM_OK;
+    }
+    const bool has_s = face_south(c), has_n = face_north(c);
+    const int E = L.depth > 1 ? (c->slide ? GR : c->pair_ty) : GR;   // one tile band / one band of the sliding kernel
+    int e0 = has_s ? E : 0, e1 = has_n ? E : 0;
+    if (e0 + e1 >= c->nyl) { e0 = c->nyl; e1 = 0; }          // short strip: everything is edge
+    HIPCHK(hipEventRecord(c->ev_main, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_main, 0));
+    if (c->comm_issued) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_edge, 0));   // ev_edge still is the previous group's
+    int rc = wait_for_neighbour_pulls();
     if (rc) return rc;
-    c->cur = dst;
-    c->steps_done = t + depth;
+    a.reverse = 0;
+    a.y_lo = 0; a.y_cnt = e0; a.y_lo2 = c->nyl - e1; a.y_cnt2 = e1;
+    if (e0 == 0) { a.y_lo = a.y_lo2; a.y_cnt = e1; a.y_cnt2 = 0; }
+    launch_depth<T>(c, a, L.depth, c->comm_stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev_edge, c->comm_stream));
+    c->edge_rows[0] = e0; c->edge_rows[1] = e1;
+    return LBM_OK;
+}
+
+// Everything of a launch that follows its exchange, and the bookkeeping.
+template <typename T>
+int issue_after(lbm_ctx* c, const Launch& L) {
+    if (L.kind == KIND_EXCHANGE) {
+        HIPCHK(hipEventRecord(c->ev_comm, exchange_stream(c)));
+        c->comm_issued = true;
+        if (c->overlap) {
+            const int e0 = c->edge_rows[0], e1 = c->edge_rows[1];
+            if (c->nyl - e0 - e1 > 0) {
+                KArgs<T> a = make_kargs<T>(c, L.src, L.dst, L.t);
+                a.y_lo = e0; a.y_cnt = c->nyl - e0 - e1;
+                a.reverse = (c->alternate && (c->launches_total & 1)) ? 1 : 0;
+                launch_depth<T>(c, a, L.depth, c->stream);
+                HIPCHK(hipGetLastError());
+            }
+        }
+    }
+    c->mid_pair = (L.kind == KIND_EXTENDED);
+    c->cur = L.dst;
+    c->steps_done = L.t + L.depth;
     c->launches_total++;
-    c->last_was_pair = depth > 1;
+    c->last_was_pair = L.depth > 1;
     c->restored = false;
-    return depth;
+    return LBM_OK;
+}
+
+// Advance ONE context by up to `remaining` iterations with one launch; returns the iterations taken (1..3) or <0.
+template <typename T>
+int advance(lbm_ctx* c, int remaining, int of, bool transport, bool strip_logic = true) {
+    Launch L;
+    int rc = plan_launch(c, remaining, of, transport, strip_logic, &L);
+    if (rc) return rc;
+    rc = issue_before<T>(c, L);
+    if (rc) return rc;
+    if (L.kind == KIND_EXCHANGE) {
+        rc = exchange_rccl<T>(c, L.dst, exchange_stream(c));
+        if (rc) return rc;
+    }
+    rc = issue_after<T>(c, L);
+    if (rc) return rc;
+    return L.depth;
 }
 
 // Make everything issued so far (both streams) visible to work queued on the compute stream afterwards.
@@ -553,7 +661,7 @@ int time_plan(lbm_ctx* c, float* ms_out) {
 
 template <typename T>
 int choose_plan(lbm_ctx* c) {
-    const bool strips = c->comm && c->nranks > 1;
+    const bool strips = (c->comm && c->nranks > 1) || c->group_n > 1;
     const Plan fixed = {(strips || c->loopback) ? 1 : c->layout, c->variant, c->use_nt, c->alternate, c->fuse, c->pair_ty, c->xcd,
                         "fixed by options", c->slide};
     std::vector<Plan> cand;
@@ -647,39 +755,96 @@ int do_initialise(lbm_ctx* c) {
     HIPCHK(hipMemcpyAsync(c->d_unstable, &big, sizeof(int), hipMemcpyHostToDevice, c->stream));
     rc = init_state<T>(c);
     if (rc) return rc;
-    if (c->comm || c->loopback) {
+    if ((c->comm || c->loopback) && c->group_n <= 1) {   // (a group exchanges once all members are initialised)
         rc = exchange_rccl<T>(c, c->cur, c->stream);
         if (rc) return rc;
     }
     return LBM_OK;
 }
 
+// `nsteps` iterations of n strips driven in lockstep by this thread (n == 1: a context on its own, which may talk to
+// other PROCESSES through its RCCL communicator). Per launch: every member's part before the exchange, the exchange,
+// every member's part after it.
 template <typename T>
-int do_steps(lbm_ctx* c, int nsteps, int of) {
-    if (c->timing) HIPCHK(hipEventRecord(c->ev_t0, c->stream));
-    const bool exchange = (c->comm && c->nranks > 1) || c->loopback;
+int do_steps(lbm_ctx** cs, int n, int nsteps, int of) {
+    for (int i = 0; i < n; ++i) {
+        lbm_ctx* c = cs[i];
+        HIPCHK(hipSetDevice(c->device));
+        if (c->timing) HIPCHK(hipEventRecord(c->ev_t0, c->stream));
+        if (c->steps_done != cs[0]->steps_done) return fail(LBM_ERR_ARG, "the strips of a group are at different iterations");
+    }
+    lbm_ctx* c0 = cs[0];
+    const bool transport = n > 1 || (c0->comm && c0->nranks > 1) || c0->loopback;   // a device transport is attached
     int launches = 0;
+    std::vector<Launch> L((size_t)n);
     for (int k = 0; k < nsteps;) {
-        const int t = c->steps_done;
-        if (of > 0 && t % of == 0) {
-            if (c->log_count >= c->log_cap) return fail(LBM_ERR_ARG, "force log full (%d rows): drain it", c->log_cap);
-            int rc = join_comm(c);      // the edge bands of the previous launch live on the side stream
+        const int t = c0->steps_done;
+        for (int i = 0; i < n; ++i) {
+            lbm_ctx* c = cs[i];
+            HIPCHK(hipSetDevice(c->device));
+            if (of > 0 && t % of == 0) {
+                if (c->log_count >= c->log_cap) return fail(LBM_ERR_ARG, "force log full (%d rows): drain it", c->log_cap);
+                int rc = join_comm(c);      // the edge bands of the previous launch live on the side stream
+                if (rc) return rc;
+                rc = launch_forces<T>(c, c->d_force_log + 3L * c->log_count, t);
+                if (rc) return rc;
+                c->log_count++;
+            }
+            int rc = plan_launch(c, nsteps - k, of, transport, true, &L[i]);
             if (rc) return rc;
-            rc = launch_forces<T>(c, c->d_force_log + 3L * c->log_count, t);
+            if (L[i].depth != L[0].depth || L[i].kind != L[0].kind)
+                return fail(LBM_ERR_ARG, "the strips of a group disagree on the next launch (different options?)");
+            rc = issue_before<T>(c, L[i]);
             if (rc) return rc;
-            c->log_count++;
         }
-        const int took = advance<T>(c, nsteps - k, of, exchange);   // exchange == a device transport is attached
-        if (took < 0) return took;
-        k += took;
+        if (L[0].kind == KIND_EXCHANGE) {
+            int rc = n > 1 ? exchange_group<T>(cs, n, L[0].dst) : exchange_rccl<T>(c0, L[0].dst, exchange_stream(c0));
+            if (rc) return rc;
+        }
+        for (int i = 0; i < n; ++i) {
+            HIPCHK(hipSetDevice(cs[i]->device));
+            int rc = issue_after<T>(cs[i], L[i]);
+            if (rc) return rc;
+        }
+        k += L[0].depth;
         ++launches;
     }
-    if (c->timing) {
+    for (int i = 0; i < n; ++i) {
+        lbm_ctx* c = cs[i];
+        if (!c->timing) continue;
+        HIPCHK(hipSetDevice(c->device));
         int jr = join_comm(c);
         if (jr) return jr;
         HIPCHK(hipEventRecord(c->ev_t1, c->stream));
         c->timed_launches = launches;
         c->timed_steps = nsteps;
+    }
+    return LBM_OK;
+}
+
+// The halos of a freshly initialised / restored group: every member's edge rows of buf[cur] to its neighbours.
+template <typename T>
+int refresh_group_halos(lbm_ctx** cs, int n) {
+    for (int i = 0; i < n; ++i) {
+        lbm_ctx* c = cs[i];
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipStreamSynchronize(c->comm_stream));
+        HIPCHK(hipEventRecord(c->ev_edge, exchange_stream(c)));
+        if (c->cur != cs[0]->cur) return fail(LBM_ERR_ARG, "the strips of a group are in different buffer phases");
+    }
+    int rc = exchange_group<T>(cs, n, cs[0]->cur);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        lbm_ctx* c = cs[i];
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipEventRecord(c->ev_comm, exchange_stream(c)));
+        c->comm_issued = true;
+        c->mid_pair = false;
+    }
+    for (int i = 0; i < n; ++i) {
+        HIPCHK(hipSetDevice(cs[i]->device));
+        HIPCHK(hipStreamSynchronize(exchange_stream(cs[i])));
     }
     return LBM_OK;
 }
@@ -924,6 +1089,8 @@ void lbm_destroy(lbm_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm) ncclCommDestroy(c->comm);
+    for (lbm_ctx* nb : {c->nb_south, c->nb_north})   // a destroyed member leaves its group
+        if (nb) { if (nb->nb_south == c) nb->nb_south = nullptr; if (nb->nb_north == c) nb->nb_north = nullptr; }
     void* ptrs[] = {c->buf[0], c->buf[1], c->scratch, c->d_macro, c->d_maxbits, c->d_unstable, c->d_solid_count, c->d_feq,
                     c->d_force_now, c->d_force_log, c->d_halo, c->d_red};
     for (void* q : ptrs)
@@ -959,8 +1126,9 @@ int lbm_initialise(lbm_ctx* c, int* solid_count_out) {
 int lbm_step(lbm_ctx* c, int nsteps, int output_frequency) {
     if (!c || !c->initialised) return fail(LBM_ERR_ARG, "context not initialised");
     if (nsteps < 0) return fail(LBM_ERR_ARG, "nsteps < 0");
+    if (c->group_n > 1) return fail(LBM_ERR_ARG, "this context is a member of a group: use lbm_group_step");
     HIPCHK(hipSetDevice(c->device));
-    return DISPATCH(c, do_steps<double>(c, nsteps, output_frequency), do_steps<float>(c, nsteps, output_frequency));
+    return DISPATCH(c, do_steps<double>(&c, 1, nsteps, output_frequency), do_steps<float>(&c, 1, nsteps, output_frequency));
 }
 
 int lbm_sync(lbm_ctx* c) {
@@ -1098,6 +1266,100 @@ int lbm_comm_allreduce(lbm_ctx* c, double* vals, int n, int op) {
     return LBM_OK;
 }
 
+// ---- in-process groups of strips ----------------------------------------------------------------------------
+namespace {
+int check_group(lbm_ctx** cs, int n, bool linked) {
+    if (!cs || n < 1) return fail(LBM_ERR_ARG, "empty group");
+    for (int k = 0; k < n; ++k) {
+        if (!cs[k]) return fail(LBM_ERR_ARG, "null context in group");
+        if (linked && (cs[k]->group_n != n || cs[k]->group_k != k)) return fail(LBM_ERR_ARG, "not the group these contexts were linked as");
+    }
+    return LBM_OK;
+}
+}  // namespace
+
+int lbm_group_link(lbm_ctx** cs, int n, int transport) {
+    int rc = check_group(cs, n, false);
+    if (rc) return rc;
+    if (transport != 0 && transport != 1) return fail(LBM_ERR_ARG, "transport must be 0 (peer copies) or 1 (RCCL)");
+    for (int k = 0; k < n; ++k) {
+        lbm_ctx* c = cs[k];
+        if (c->initialised || c->comm || c->group_n > 1) return fail(LBM_ERR_ARG, "link fresh contexts (before lbm_initialise, without a communicator)");
+        if (c->p.precision != cs[0]->p.precision || c->nx != cs[0]->nx || c->p.ny != cs[0]->p.ny)
+            return fail(LBM_ERR_ARG, "the strips of a group must share nx, ny and the precision");
+        const int expect = k == 0 ? 0 : cs[k - 1]->p.y_start + cs[k - 1]->nyl;
+        if (c->p.y_start != expect) return fail(LBM_ERR_ARG, "strip %d starts at row %d, expected %d (bottom to top, contiguous)", k, c->p.y_start, expect);
+        if (n > 1 && c->nyl < 2 * GR) return fail(LBM_ERR_ARG, "a strip with neighbours needs at least %d rows", 2 * GR);
+    }
+    if (cs[n - 1]->p.y_start + cs[n - 1]->nyl != cs[0]->p.ny) return fail(LBM_ERR_ARG, "the strips do not cover all %d rows", cs[0]->p.ny);
+    if (n == 1) return LBM_OK;
+    if (transport == 1) {   // one communicator per member, created together (ncclCommInitAll wants distinct devices)
+        std::vector<int> devs((size_t)n);
+        std::vector<ncclComm_t> comms((size_t)n);
+        for (int k = 0; k < n; ++k) devs[(size_t)k] = cs[k]->device;
+        NCCLCHK(ncclCommInitAll(comms.data(), n, devs.data()));
+        for (int k = 0; k < n; ++k) { cs[k]->comm = comms[(size_t)k]; cs[k]->rank = k; cs[k]->nranks = n; }
+    } else {
+        for (int k = 0; k < n; ++k) {
+            lbm_ctx* c = cs[k];
+            HIPCHK(hipSetDevice(c->device));
+            for (lbm_ctx* nb : {k > 0 ? cs[k - 1] : nullptr, k + 1 < n ? cs[k + 1] : nullptr}) {
+                if (!nb || nb->device == c->device) continue;
+                int can = 0;
+                HIPCHK(hipDeviceCanAccessPeer(&can, c->device, nb->device));
+                if (can) {
+                    const hipError_t e = hipDeviceEnablePeerAccess(nb->device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(LBM_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d): %s", c->device, nb->device, hipGetErrorString(e));
+                    (void)hipGetLastError();
+                }   // (without peer access hipMemcpyPeerAsync stages through the host)
+            }
+            // the neighbours' streams wait on these events and read what the kernels before them wrote: system-scope release
+            for (hipEvent_t* ev : {&c->ev_edge, &c->ev_comm}) {
+                HIPCHK(hipEventDestroy(*ev));
+                HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+            }
+        }
+    }
+    for (int k = 0; k < n; ++k) {
+        cs[k]->nb_south = k > 0 ? cs[k - 1] : nullptr;
+        cs[k]->nb_north = k + 1 < n ? cs[k + 1] : nullptr;
+        cs[k]->group_transport = transport;
+        cs[k]->group_n = n;
+        cs[k]->group_k = k;
+    }
+    return LBM_OK;
+}
+
+int lbm_group_initialise(lbm_ctx** cs, int n, int* solid_total) {
+    int rc = check_group(cs, n, true);
+    if (rc) return rc;
+    int total = 0;
+    for (int k = 0; k < n; ++k) {
+        int sc = 0;
+        rc = lbm_initialise(cs[k], &sc);
+        if (rc) return rc;
+        total += sc;
+    }
+    if (solid_total) *solid_total = total;
+    if (n > 1) rc = DISPATCH(cs[0], refresh_group_halos<double>(cs, n), refresh_group_halos<float>(cs, n));
+    return rc;
+}
+
+int lbm_group_step(lbm_ctx** cs, int n, int nsteps, int output_frequency) {
+    int rc = check_group(cs, n, true);
+    if (rc) return rc;
+    if (nsteps < 0) return fail(LBM_ERR_ARG, "nsteps < 0");
+    for (int k = 0; k < n; ++k)
+        if (!cs[k]->initialised) return fail(LBM_ERR_ARG, "context not initialised");
+    return DISPATCH(cs[0], do_steps<double>(cs, n, nsteps, output_frequency), do_steps<float>(cs, n, nsteps, output_frequency));
+}
+
+int lbm_group_refresh_halos(lbm_ctx** cs, int n) {
+    int rc = check_group(cs, n, true);
+    if (rc || n == 1) return rc;
+    return DISPATCH(cs[0], refresh_group_halos<double>(cs, n), refresh_group_halos<float>(cs, n));
+}
+
 int lbm_halo_export(lbm_ctx* c, double* south_out, double* north_out) {
     if (!c || !c->initialised) return fail(LBM_ERR_ARG, "context not initialised");
     HIPCHK(hipSetDevice(c->device));
@@ -1156,7 +1418,8 @@ int lbm_load_state(lbm_ctx* c, const char* path) {
     c->log_count = 0;
     c->last_was_pair = false;
     c->mid_pair = false;
-    if (c->comm || c->loopback) rc = DISPATCH(c, exchange_rccl<double>(c, c->cur, c->stream), exchange_rccl<float>(c, c->cur, c->stream));
+    if ((c->comm || c->loopback) && c->group_n <= 1)   // (a group: lbm_group_refresh_halos once every member is restored)
+        rc = DISPATCH(c, exchange_rccl<double>(c, c->cur, c->stream), exchange_rccl<float>(c, c->cur, c->stream));
     return rc;
 }
 

@@ -111,6 +111,20 @@ int  lbm_comm_init(lbm_ctx* c, int rank, int nranks, const void* id128);
 /* Sum the partial force sums / max / min across strips (the reference's MPI_Reduce/MPI_Allreduce at
  * LBMIO.h:167-168, LBMGrid.h:315,342). In place, host values, n doubles. op: 0 sum, 1 max, 2 min. */
 int  lbm_comm_allreduce(lbm_ctx* c, double* vals, int n, int op);
+/* In-process strips (replaces the decomposition Grid::initialise_2d_topology builds, LBMGrid.h:347-392, when ONE process
+ * drives several GPUs, e.g. `lbm_solver --gpus 8`): n contexts created for consecutive strips (bottom to top, covering
+ * all ny rows; any devices) are linked into a group and then initialised and stepped together by the calling thread.
+ * transport 0: every strip pulls its neighbours' edge rows with hipMemcpyPeerAsync over xGMI (plain device copies when
+ * two strips share a device) on its side stream, behind the neighbour's edge-rows event; transport 1: RCCL, one
+ * communicator per member (ncclCommInitAll; distinct devices), all members' ncclSend/ncclRecv in one group call.
+ * The launch sequence, the exchange cadence and the overlap are those of lbm_step. Per-strip results
+ * (lbm_get_macros, lbm_drain_force_log, lbm_first_unstable_step, ...) are read member by member and combined by the
+ * caller (sum of forces, min of the unstable step, rows concatenated by y_start: LBMSolver.h:269-362, LBMIO.h:167-168).
+ * lbm_group_refresh_halos: after lbm_load_state on every member. */
+int  lbm_group_link(lbm_ctx** ctxs, int n, int transport);
+int  lbm_group_initialise(lbm_ctx** ctxs, int n, int* solid_total_out);
+int  lbm_group_step(lbm_ctx** ctxs, int n, int nsteps, int output_frequency);
+int  lbm_group_refresh_halos(lbm_ctx** ctxs, int n);
 /* Host-staged path (the buffers the reference hands to MPI_Isend/Irecv, LBMGrid.h:255-276). Each face buffer is
  * [LBM_HALO_ROWS][9][nx] doubles: the LBM_HALO_ROWS (= 6) interior rows next to that face, bottom row first, all nine
  * populations (six rows: up to two launches of up to three fused iterations each may run between two exchanges, the

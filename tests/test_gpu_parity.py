@@ -339,6 +339,65 @@ def test_overlap_choreography_with_loopback_halo(lbm, pair):
         assert out[0][1] == other[1] and out[0][2] == other[2]
 
 
+@pytest.mark.parametrize("overlap,deep", [(1, 1), (0, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("plan", ["rowil-fuse3-12-nt-xcd", "rowil-slide3", "rowil-site-nt", "fast-rowil-slide2"])
+def test_group_of_strips_on_one_device_matches_single_domain_bitwise(lbm, plan, overlap, deep):
+    """In-process strips (lbm_group_*, the transport `lbm_solver --gpus N` uses) with the production choreography: edge
+    bands on the side stream, every strip PULLING its neighbours' edge rows with exactly the pointers / offsets / counts
+    of the RCCL branch (FaceSpans: top_rows -> ghost_s, bot_rows -> ghost_n), interior rows overlapped, extended first
+    launch of a pair. Three uneven strips share the one GPU of the box (the peer copy degenerates to a device copy) and
+    must reproduce the one-domain run bit for bit, for every overlap / halo-depth schedule."""
+    nx, ny, steps, of = 320, 100, 271, 45
+    kw = dict(inlet_velocity=0.06, cylinder_radius=0.12)
+    opts = dict(PLANS[plan], overlap=overlap, deep_halo=deep)
+    with lbm.Context(nx, ny, options=PLANS[plan], **kw) as whole:
+        solid = whole.initialise()
+        whole.step(steps, of)
+        w = (whole.macros(), whole.populations("f_next"), whole.populations("f_current"), whole.drain_force_log(),
+             whole.forces(), whole.max_velocity_sq())
+    with lbm.Group(nx, ny, [(0, 37), (37, 22), (59, 41)], options=opts, **kw) as g:
+        assert g.initialise() == solid
+        g.step(steps, of)
+        assert g.first_unstable_step() == -1 and g.steps_done == steps
+        for u, v in zip(g.macros(), w[0]):
+            assert np.array_equal(u, v)
+        assert np.array_equal(g.populations("f_next"), w[1])
+        assert np.array_equal(g.populations("f_current")[1:-1], w[2][1:-1])
+        log = g.drain_force_log()
+        assert [r[0] for r in log] == [r[0] for r in w[3]]
+        for (t, fx, fy), (_, wx, wy) in zip(log, w[3]):
+            assert abs(fx - wx) <= 1e-13 * max(1.0, abs(wx)) and abs(fy - wy) <= 1e-13
+        fx, fy = g.forces()
+        assert abs(fx - w[4][0]) <= 1e-13 * max(1.0, abs(w[4][0])) and abs(fy - w[4][1]) <= 1e-13
+        assert g.max_velocity_sq() == w[5]
+        with pytest.raises(lbm.LbmError, match="member of a group"):
+            g.ctxs[0].step(1, 0)
+
+
+def test_group_checkpoint_restart(lbm, tmp_path):
+    """Per-strip checkpoints of a group, restored into a fresh group (lbm_group_refresh_halos), continue bit-exactly."""
+    nx, ny = 256, 96
+    kw = dict(inlet_velocity=0.07, cylinder_radius=0.1)
+    with lbm.Group(nx, ny, 3, options=PLANS["rowil-slide3"], **kw) as a:
+        a.initialise()
+        a.step(137, 0)
+        for k, c in enumerate(a.ctxs):
+            c.save_state(tmp_path / f"s{k}.ckpt")
+        a.step(200, 50)
+        ref = (a.macros(), a.populations("f_next"), a.drain_force_log())
+    with lbm.Group(nx, ny, 3, options=PLANS["rowil-fuse3-12-nt-xcd"], **kw) as b:
+        b.initialise()
+        for k, c in enumerate(b.ctxs):
+            c.load_state(tmp_path / f"s{k}.ckpt")
+        b.refresh_halos()
+        assert b.steps_done == 137
+        b.step(200, 50)
+        got = (b.macros(), b.populations("f_next"), b.drain_force_log())
+    for u, v in zip(ref[0], got[0]):
+        assert np.array_equal(u, v)
+    assert np.array_equal(ref[1], got[1]) and ref[2] == got[2]
+
+
 def test_checkpoint_restart_is_bit_exact(lbm, tmp_path):
     """Save at iteration 137, restore into a fresh context (different plan), continue: identical to the uninterrupted run."""
     nx, ny = 256, 96
