@@ -54,6 +54,7 @@ def lib():
         L.lbm_get_macros.argtypes = [vp, dp, dp, dp]
         L.lbm_max_velocity_sq.argtypes = [vp, dp]
         L.lbm_get_populations.argtypes = [vp, C.c_int, dp]
+        L.lbm_set_f_current.argtypes = [vp, dp]
         L.lbm_get_solid.argtypes = [vp, C.POINTER(C.c_ubyte)]
         L.lbm_comm_unique_id.argtypes = [vp]
         L.lbm_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -180,6 +181,12 @@ class Context:
         out = np.empty((self.local_ny + 2, self.nx + 2, 9), dtype=np.float64)
         self._chk(self.L.lbm_get_populations(self.h, {"f_current": 0, "f_next": 1}[which], _dp(out)))
         return out
+
+    def set_f_current(self, aos):
+        """Write side of Grid::f_current: [(local_ny+2), (nx+2), 9]; interior cells replace the pre-collision state."""
+        a = np.ascontiguousarray(aos, dtype=np.float64)
+        assert a.shape == (self.local_ny + 2, self.nx + 2, 9)
+        self._chk(self.L.lbm_set_f_current(self.h, _dp(a)))
 
     def solid(self):
         m = np.empty((self.local_ny, self.nx), dtype=np.uint8)

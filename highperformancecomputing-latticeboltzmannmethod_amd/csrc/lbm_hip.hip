@@ -937,6 +937,27 @@ int do_halo_import(lbm_ctx* c, const double* south_in, const double* north_in) {
     return LBM_OK;
 }
 
+// Grid::f_current(x,y,i) written by a client (LBMGrid.h:115): the pre-collision state of the next iteration. The interior
+// cells of `aos` are packed into the scratch buffer and re-collided into buf[cur] (collision_step skips solid cells).
+template <typename T>
+int do_set_f_current(lbm_ctx* c, const double* aos) {
+    if (!c->scratch) HIPCHK(hipMalloc(&c->scratch, buffer_bytes(c)));
+    std::vector<T> host(c->total);
+    const int tnx = c->nx + 2;
+    for (int y = 0; y < c->nyl; ++y)
+        for (int x = 0; x < c->nx; ++x) {
+            const double* v = aos + ((size_t)(y + 1) * tnx + (x + 1)) * Q;
+            for (int i = 0; i < Q; ++i) host[(size_t)i * c->plane + (size_t)(y + GR) * c->pitch + c->xoff + x] = (T)v[i];
+        }
+    HIPCHK(hipMemcpyAsync(c->scratch, host.data(), c->total * c->esize, hipMemcpyHostToDevice, c->stream));
+    KArgs<T> a = make_kargs<T>(c, c->cur, c->cur, c->steps_done);
+    a.src = static_cast<const T*>(c->scratch);
+    launch_rows<T, MODE_COLLIDE_ONLY>(c, a, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LBM_OK;
+}
+
 #define DISPATCH(c, call_d, call_f) ((c)->p.precision == LBM_PRECISION_F32 ? (call_f) : (call_d))
 
 }  // namespace
@@ -1219,6 +1240,18 @@ int lbm_get_populations(lbm_ctx* c, int which, double* aos) {
     HIPCHK(hipSetDevice(c->device));
     { int jr = join_comm(c); if (jr) return jr; }
     return DISPATCH(c, do_populations<double>(c, which, aos), do_populations<float>(c, which, aos));
+}
+
+int lbm_set_f_current(lbm_ctx* c, const double* aos) {
+    if (!c || !c->initialised || !aos) return fail(LBM_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->comm_stream));
+    int rc = DISPATCH(c, do_set_f_current<double>(c, aos), do_set_f_current<float>(c, aos));
+    if (rc) return rc;
+    if ((c->comm || c->loopback) && c->group_n <= 1)   // (a group: lbm_group_refresh_halos once every member is set)
+        rc = DISPATCH(c, exchange_rccl<double>(c, c->cur, c->stream), exchange_rccl<float>(c, c->cur, c->stream));
+    return rc;
 }
 
 int lbm_get_solid(lbm_ctx* c, unsigned char* mask) {

@@ -37,7 +37,12 @@ struct SimulationParams {
 
 // Build-side run options that the reference does not have (it hard-codes everything in main.cpp:11-12).
 struct BackendOptions {
-    int device = 0;
+    int device = 0;               // first device; strip k runs on device (device + k) % visible devices ...
+    int gpus = 1;                 // ... of the `gpus` devices used (clamped to the devices present)
+    int strips = 0;               // row strips the lattice is cut into (0: one per GPU); > gpus: several strips share a GPU
+    bool rccl = false;            // strip halos through RCCL (one communicator per strip; needs strips == gpus) instead of
+                                  // peer copies over xGMI
+    bool contracted = false;      // collision arithmetic: FMA-contracted + one reciprocal (lbm_set_option "arith" 1)
     bool fp32 = false;            // single-precision populations (build-only variant)
     bool tune = true;             // measured plan at initialise (lbm_set_option "tune")
     bool async_vtk = true;        // write VTK frames on a writer thread

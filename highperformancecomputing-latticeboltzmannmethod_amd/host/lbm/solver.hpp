@@ -78,6 +78,7 @@ public:
     void save_state(const std::string& path) const { grid_.save_state(path); }
 
     const Grid& get_grid() const { return grid_; }
+    Grid& get_grid() { return grid_; }   // (the reference's Solver reaches its Grid's mutable accessors as a member)
     const SimulationParams& get_params() const { return params_; }
 
 private:

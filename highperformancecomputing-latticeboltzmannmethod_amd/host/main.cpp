@@ -14,10 +14,14 @@
 static void usage() {
     std::puts("lbm_solver [--nx N] [--ny N] [--steps N] [--output-frequency N] [--tau X] [--inlet-velocity X]\n"
               "           [--reynolds RE] [--cylinder-x F] [--cylinder-y F] [--cylinder-radius F] [--vtk-start-step N]\n"
-              "           [--no-vtk] [--no-final] [--sync-vtk] [--fp32] [--no-tune] [--device D] [--quiet]\n"
+              "           [--no-vtk] [--no-final] [--sync-vtk] [--fp32] [--contracted] [--no-tune] [--device D] [--quiet]\n"
+              "           [--gpus N] [--strips N] [--rccl]\n"
               "           [--checkpoint FILE] [--restart FILE]\n"
               "Defaults are the reference's SimulationParams (LBMConfig.h:37-51). --reynolds sets the inlet velocity\n"
-              "from tau and the cylinder diameter so that params.reynolds() equals RE.");
+              "from tau and the cylinder diameter so that params.reynolds() equals RE.\n"
+              "--gpus N cuts the lattice into N row strips, one per GPU of this node, advanced in lockstep by this process\n"
+              "with the halo rows copied GPU to GPU over xGMI (--rccl: RCCL send/recv instead); --strips M > N puts several\n"
+              "strips on one GPU. --contracted: FMA-contracted collision (as the reference's -ffast-math -mfma build).");
 }
 
 int main(int argc, char** argv) {
@@ -48,6 +52,10 @@ int main(int argc, char** argv) {
         else if (k == "--sync-vtk") opt.async_vtk = false;
         else if (k == "--fp32") opt.fp32 = true;
         else if (k == "--no-tune") opt.tune = false;
+        else if (k == "--contracted") opt.contracted = true;
+        else if (k == "--gpus") opt.gpus = std::atoi(val());
+        else if (k == "--strips") opt.strips = std::atoi(val());
+        else if (k == "--rccl") opt.rccl = true;
         else if (k == "--device") opt.device = std::atoi(val());
         else if (k == "--quiet") opt.quiet = true;
         else if (k == "--restart") restart_from = val();

@@ -11,17 +11,26 @@
 #include <vector>
 
 int main(int argc, char** argv) {
-    if (argc < 6) { std::fprintf(stderr, "usage: surface_dump nx ny steps output_frequency out.bin\n"); return 2; }
+    if (argc < 6) { std::fprintf(stderr, "usage: surface_dump nx ny steps output_frequency out.bin [strips [poke_at_step]]\n"); return 2; }
     LBM::SimulationParams p;
     p.nx = std::atoi(argv[1]); p.ny = std::atoi(argv[2]); p.num_timesteps = std::atoi(argv[3]);
     p.output_frequency = std::atoi(argv[4]);
     LBM::BackendOptions opt;
     opt.quiet = true;
+    if (argc > 6) opt.strips = std::atoi(argv[6]);         // several row strips behind the one Grid (on the GPUs present)
+    const int poke_at = argc > 7 ? std::atoi(argv[7]) : -1;
     LBM::Solver solver(p, false, opt);
     LBM::IOManager io;
     solver.initialise();
-    for (int t = 0; t < p.num_timesteps; ++t)
+    for (int t = 0; t < p.num_timesteps; ++t) {
+        if (t == poke_at) {                                // a client writing through Grid::f_current (LBMGrid.h:115)
+            LBM::Grid& gw = solver.get_grid();
+            const int cx = gw.local_nx() / 2 + 1, cy = gw.local_ny() / 2 + 1;   // ghost-inclusive coordinates
+            gw.f_current(cx, cy, 1) += 1e-3;
+            gw.f_current_ptr(cx + 3, cy - 2)[5] *= 1.01;
+        }
         if (!solver.step(t, io)) return 1;                 // the loop body of the reference's run(), one call each
+    }
     const LBM::Grid& g = solver.get_grid();
     std::FILE* fp = std::fopen(argv[5], "wb");
     if (!fp) return 3;

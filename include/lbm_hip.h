@@ -98,6 +98,11 @@ int  lbm_max_velocity_sq(lbm_ctx* c, double* out);
 /* Debug/parity accessor: ghost-inclusive AoS [(local_ny+2)][(nx+2)][9] exactly as Grid::f_current /
  * Grid::f_next index it (LBMGrid.h:105-107,116-119). which: 0 = f_current, 1 = f_next. */
 int  lbm_get_populations(lbm_ctx* c, int which, double* aos);
+/* The write side of Grid::f_current (LBMGrid.h:115: `double& f_current(x,y,i)`): replaces the pre-collision state of the
+ * next iteration by the interior cells of `aos` (same ghost-inclusive layout as lbm_get_populations; ghost entries are
+ * ignored, they belong to the halo logic) and redoes collision_step() on it. Custom initial conditions enter here.
+ * Until the next lbm_step the snapshots still show the values before the call. Synchronises. */
+int  lbm_set_f_current(lbm_ctx* c, const double* aos);
 /* Grid::is_solid (LBMGrid.h:146-148) for this strip, [local_ny][nx] bytes. */
 int  lbm_get_solid(lbm_ctx* c, unsigned char* mask);
 

@@ -59,6 +59,48 @@ def test_lbm_solver_files_match_reference(extra):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--strips", "2"], ["--strips", "2", "--sync-vtk", "--contracted"]])
+def test_lbm_solver_with_strips_writes_the_reference_files(extra):
+    """Multi-GPU behind the C++ surface (`lbm_solver --gpus N`; here N strips share the box's one GPU): strip Grids
+    advanced in lockstep, force partial sums added, strip macros concatenated for VTK / velocity_field.csv, stability =
+    min over strips. The files must equal the unmodified reference's (golden g9), exactly as for one strip."""
+    g = load_golden("g9_files_64x32_s1201")
+    d = tempfile.mkdtemp(prefix="lbm_host_")
+    cmd = [EXE, "--nx", "64", "--ny", "32", "--steps", "1201", "--output-frequency", "400", "--inlet-velocity", "0.04",
+           "--cylinder-radius", "0.1", "--no-tune"] + extra
+    pr = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    assert f"row strips: {extra[1]}" in pr.stdout
+    same_text(open(os.path.join(d, "forces.csv")).read(), bytes(g["forces_csv"]).decode())
+    same_text(open(os.path.join(d, "velocity_field.csv")).read(), bytes(g["velocity_field_csv"]).decode())
+    same_text(open(os.path.join(d, "simulation_params.csv")).read(), bytes(g["simulation_params_csv"]).decode())
+    assert sorted(os.listdir(os.path.join(d, "vtk_output"))) == list(g["vtk_names"])
+    same_text(open(os.path.join(d, "vtk_output", "lbm_001200.vtk")).read(), bytes(g["vtk_last"]).decode())
+    assert [l for l in pr.stdout.splitlines() if l.startswith("Timestep ")] == \
+           [l for l in str(g["stdout"]).splitlines() if l.startswith("Timestep ")]
+    assert "Solid cells: 29" in pr.stdout and "Simulation completed successfully!" in pr.stdout
+
+
+@pytest.mark.gpu
+def test_lbm_solver_strips_checkpoint_restart_and_instability():
+    g = load_golden("g9_files_64x32_s1201")
+    base = ["--nx", "64", "--ny", "32", "--output-frequency", "400", "--inlet-velocity", "0.04", "--cylinder-radius", "0.1",
+            "--no-vtk", "--quiet", "--strips", "2"]
+    d = tempfile.mkdtemp(prefix="lbm_host_")
+    subprocess.run([EXE] + base + ["--steps", "600", "--checkpoint", "s.ckpt", "--no-final"], cwd=d, check=True, timeout=300,
+                   stdout=subprocess.DEVNULL)
+    assert sorted(f for f in os.listdir(d) if f.startswith("s.ckpt")) == ["s.ckpt.0", "s.ckpt.1"]
+    subprocess.run([EXE] + base + ["--steps", "1201", "--restart", "s.ckpt"], cwd=d, check=True, timeout=300,
+                   stdout=subprocess.DEVNULL)
+    same_text(open(os.path.join(d, "velocity_field.csv")).read(), bytes(g["velocity_field_csv"]).decode())
+    gu = load_golden("g8b_unstable_128x32")
+    pr = subprocess.run([EXE, "--nx", "128", "--ny", "32", "--steps", "2000", "--output-frequency", "50", "--tau", "0.51",
+                         "--inlet-velocity", "0.15", "--no-vtk", "--quiet", "--strips", "2"], cwd=d, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, text=True, timeout=300)
+    assert pr.returncode == 1 and f"Simulation unstable at timestep {int(gu['unstable_t'])}" in pr.stderr
+
+
+@pytest.mark.gpu
 def test_lbm_solver_reports_instability_like_the_reference():
     g = load_golden("g8b_unstable_128x32")
     d = tempfile.mkdtemp(prefix="lbm_host_")
@@ -119,3 +161,36 @@ def test_cpp_surface_accessors_match_reference_values():
     assert linf_rel(fc, g["f_current"]) < 1e-10 and linf_rel(fn, g["f_next"]) < 1e-10
     assert np.array_equal(solid, g["solid"]) and abs(mv - float(g["max_velocity"][0])) < 1e-10
     same_text(open(os.path.join(d, "forces.csv")).read(), str(g["forces_text"]))
+    # the same client on a Grid of two strips (32 rows: a strip with neighbours needs 12): identical bytes
+    subprocess.run([exe, str(nx), str(ny), "100", "50", "dump2.bin", "2"], cwd=d, check=True, timeout=300)
+    assert open(os.path.join(d, "dump2.bin"), "rb").read() == raw
+
+
+@pytest.mark.gpu
+def test_cpp_surface_write_through_f_current_matches_oracle():
+    """Grid's mutable accessors (LBMGrid.h:113-122: `double& f_current(x,y,i)`, `f_current_ptr`): a client perturbs two
+    populations after iteration 39 and goes on; the result must equal the oracle's with the same two writes."""
+    from oracle.oracle import Oracle, make_params
+    from tests.helpers import macro_errors, linf_rel
+    nx, ny, steps, poke = 96, 40, 80, 40
+    exe = os.path.join(ROOT, PKG, "host", "surface_dump")
+    o = Oracle(make_params(nx, ny))
+    assert o.run(poke) == -1
+    fc = o.f_current
+    cx, cy = nx // 2 + 1, ny // 2 + 1
+    fc[cy, cx, 1] += 1e-3
+    fc[cy - 2, cx + 3, 5] *= 1.01
+    assert o.run(steps - poke) == -1
+    for strips in ("1", "2"):
+        d = tempfile.mkdtemp(prefix="lbm_host_")
+        subprocess.run([exe, str(nx), str(ny), str(steps), "1000", "dump.bin", strips, str(poke)], cwd=d, check=True, timeout=300)
+        raw = open(os.path.join(d, "dump.bin"), "rb").read()
+        n, nf = nx * ny, (nx + 2) * (ny + 2) * 9
+        rho, ux, uy = (np.frombuffer(raw[16 + 8 * n * k:16 + 8 * n * (k + 1)], dtype=np.float64).reshape(ny, nx) for k in range(3))
+        fn = np.frombuffer(raw[16 + 24 * n + 8 * nf:16 + 24 * n + 16 * nf], dtype=np.float64).reshape(ny + 2, nx + 2, 9)
+        er, eu = macro_errors(rho, ux, uy, o.rho, o.ux, o.uy)
+        assert er < 1e-10 and eu < 1e-10, (strips, er, eu)
+        assert np.array_equal(fn[1:-1, 1:-1], o.f_next[1:-1, 1:-1])       # and it did change the flow:
+    o2 = Oracle(make_params(nx, ny))
+    o2.run(steps)
+    assert linf_rel(o2.rho, o.rho) > 1e-6
