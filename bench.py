@@ -5,16 +5,22 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one loop body of Solver::run (exchange + stream + BCs + stability + collision, one fused kernel
-launch) over the whole lattice. Workload at every N: BASELINE.json configs[2], the 4096x1024 fp64 cylinder at
-Re=200 (tau=0.6, u_in=0.06510417) — the grid the metric is quoted on ("4096x1024 D2Q9 at 1/2/4/8 GPUs"), so
-N>1 is STRONG scaling: the rows are cut into N strips, one process per GPU, edge rows exchanged with RCCL
-send/recv after every launch (a launch fuses up to three iterations). Populations are resident in HBM before the timed region; nothing is copied to the host
-inside it and no output (forces/VTK) step falls inside it.
+A "step" is one loop body of Solver::run (exchange + stream + BCs + stability + collision) over the whole lattice; the
+library fuses up to three consecutive steps into one kernel launch (intermediate states in LDS). Workload at every N:
+BASELINE.json configs[2], the 4096x1024 fp64 cylinder at Re=200 (tau=0.6, u_in=0.06510417) — the grid the metric is
+quoted on ("4096x1024 D2Q9 at 1/2/4/8 GPUs"), so N>1 is STRONG scaling: the rows are cut into N strips, one process per
+GPU, LBM_HALO_ROWS edge rows x 9 populations per face exchanged with RCCL send/recv once per two launches (schedule
+measured at initialise). Populations are resident in HBM before the timed region; nothing is copied to the host inside
+it and no output (forces/VTK) step falls inside it.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (live HIP-event kernel time on
-the library's own stream) and, at N=1, `cpu_baseline` (the reference binary oracle/_ref/ref_driver if it runs
-on this host, else the oracle port; bounded sample).
+Runtime hygiene: liblbm_hip.so is loaded BEFORE torch (and torch only at N>1, for the gloo rendezvous of the 128-byte
+ncclUniqueId and the barriers), so that the process binds the ROCm RCCL/HIP the library was built and tested against,
+not the copies bundled with the torch wheel; the versions actually bound are printed in the JSON line.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (live HIP-event kernel time on the
+library's own stream; `frac` = measured HBM bytes per launch / time / 8 TB/s, the 144 B-per-update figure separately) and,
+at N=1, `cpu_baseline` (the reference binary oracle/_ref/ref_driver if it runs on this host, else the oracle port;
+bounded sample).
 """
 import argparse
 import importlib
@@ -32,6 +38,8 @@ PKG = "highperformancecomputing-latticeboltzmannmethod_amd"
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_LUP = {"f64": 144, "f32": 72}   # 9 loads + 9 stores per lattice update
+CONFIGS = {(1024, 256, "f64"): "configs[1]", (4096, 1024, "f64"): "configs[2]", (8192, 2048, "f64"): "configs[3]",
+           (16384, 4096, "f32"): "configs[4]"}
 
 
 def _time_reference(ref, d, nx, ny, u_in, steps, ranks, threads, timeout=120):
@@ -95,6 +103,21 @@ def cpu_baseline(nx, ny, u_in, budget_s=12.0):
                       f"{steps} steps, {threads} OpenMP threads"}
 
 
+def measured_traffic(nx, local_ny, precision, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json; FETCH_SIZE and
+    WRITE_SIZE cannot be collected inside a timed run). Returns (bytes | None, note)."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tfile))
+    except Exception as e:
+        return None, f"profiles/traffic.json unreadable ({e})"
+    key = f"{nx}x{local_ny}_{precision}"
+    for ent in tj.get(key, []) if isinstance(tj.get(key), list) else [tj.get(key)] if tj.get(key) else []:
+        if ent.get("kernel", "").replace(" ", "") == kernel.replace(" ", ""):
+            return ent.get("hbm_bytes_per_launch"), ent.get("source", "profiles/traffic.json")
+    return None, f"no FETCH_SIZE/WRITE_SIZE pass committed for {key} with {kernel} (profiles/traffic.json)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,9 +127,12 @@ def main():
     ap.add_argument("--ny", type=int, default=1024)
     ap.add_argument("--re", type=float, default=200.0)
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--arith", choices=["contracted", "strict"], default="contracted",
+                    help="collision arithmetic: contracted = FMA + one reciprocal (what the reference's -ffast-math -mfma build "
+                         "permits; rho/u within 1e-10 of the reference, tests), strict = IEEE op by op (bit-identical to the CPU oracle)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong: the named grid cut into N strips (BASELINE metric); weak: ny rows PER GPU")
-    ap.add_argument("--variant", type=int, default=None, help="kernel variant (tuning)")
+    ap.add_argument("--set", action="append", default=[], help="library option key=value (lbm_set_option), e.g. slide=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -118,17 +144,20 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
 
-    import torch
-    import torch.distributed as dist
+    # the HIP library first: it brings in /opt/rocm's RCCL and HIP runtime before anything else can
     lbm = importlib.import_module(PKG)
+    lbm.lib()
     if lbm.device_count() < 1:
         sys.exit("no HIP device: the HIP path has no CPU fallback")
-    ndev = lbm.device_count()
-    device = local_rank % ndev          # (a launcher may expose one device per rank)
-    torch.cuda.set_device(device)
+    versions = lbm.runtime_versions()
+    dist = torch = None
     if world > 1:
+        import torch
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    ndev = lbm.device_count()
+    device = local_rank % ndev          # (a launcher may expose one device per rank)
 
     nx = args.nx
     ny_total = args.ny * (world if args.scaling == "weak" else 1)
@@ -140,8 +169,11 @@ def main():
 
     ctx = lbm.Context(nx, ny_total, tau=0.6, inlet_velocity=u_in, y_start=rank * local_ny, local_ny=local_ny,
                       precision=args.precision, device=device)
-    if args.variant is not None:
-        ctx.set_option("variant", args.variant)
+    ctx.set_option("arith", 1 if args.arith == "contracted" else 0)
+    ctx.set_option("trailing_pair", 1)      # the bench reads no snapshot: a call may end on a fused launch
+    for kv in args.set:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     if world > 1:
         ident = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
@@ -150,8 +182,9 @@ def main():
     ctx.set_option("timing", 1)
 
     def fence():
-        ctx.sync()
-        torch.cuda.synchronize()
+        ctx.sync()                       # both streams of the library (every kernel and every exchange lives on them)
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
@@ -163,6 +196,7 @@ def main():
     dt = time.perf_counter() - t0
     ms_total, launches, iterations = ctx.last_step_stats()
     kernel_ms = ms_total / max(launches, 1)            # mean duration of one launch of the dominant kernel
+    compute_only_ms = None
     if world > 1:
         tt = torch.tensor([dt, kernel_ms], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -170,42 +204,66 @@ def main():
     bad = ctx.first_unstable_step()
     if bad != -1:
         sys.exit(f"simulation unstable at timestep {bad}: result invalid")
+    if world > 1:
+        # what the halo traffic costs: the same launches with the exchange skipped (diagnostic pass, results discarded)
+        n = max(60, min(args.steps, 600))
+        ctx.set_option("skip_exchange", 1)
+        ctx.step(30, 0)
+        fence()
+        t1 = time.perf_counter()
+        ctx.step(n, 0)
+        fence()
+        tt = torch.tensor([(time.perf_counter() - t1) / n * 1e3], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        compute_only_ms = float(tt[0])
+        ctx.set_option("skip_exchange", 0)
 
     if rank == 0:
         cells = nx * ny_total
         mlups = cells * args.steps / dt / 1e6
         bpl = BYTES_PER_LUP[args.precision]
-        # dominant kernel: one launch advances this rank's strip by iterations/launches iterations (2 when two
-        # timesteps are fused through LDS); algorithmic bytes per launch = LUPs per launch x 144 B (fp64)
-        launch_bytes = int(nx * local_ny * bpl * iterations / max(launches, 1))
-        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                key = f"{nx}x{local_ny}_{args.precision}"
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        ipl = iterations / max(launches, 1)
+        # dominant kernel: one launch advances this rank's strip by `ipl` iterations (3 when three timesteps are fused
+        # through LDS); algorithmic bytes per launch = lattice updates per launch x 144 B (fp64) / 72 B (fp32)
+        launch_bytes = int(nx * local_ny * bpl * ipl)
+        kernel = ctx.kernel_name()
+        traffic, tnote = measured_traffic(nx, local_ny, args.precision, kernel)
+        equiv = launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        if traffic:
+            achieved, basis = traffic / (kernel_ms * 1e-3) / 1e9, "measured HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE) / live launch time"
+        else:   # the least a fused launch can move: read P_t once, write P_{t+d} once
+            achieved, basis = (launch_bytes / ipl) / (kernel_ms * 1e-3) / 1e9, "fused minimum (one read + one write of the lattice per launch) / live launch time; " + tnote
+        hr = lbm.Context.HALO_ROWS
+        cfg_name = CONFIGS.get((nx, ny_total, args.precision))
         line = {
             "metric": f"MLUPS ({'fp64' if args.precision == 'f64' else 'fp32'})", "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"D2Q9-BGK cylinder Re={args.re:g}, {nx}x{ny_total} {args.precision}, tau=0.6, "
-                                   f"u_in={u_in:.8f} (BASELINE.json configs[2])",
+            "config": {"workload": f"D2Q9-BGK cylinder Re={args.re:g}, {nx}x{ny_total} {args.precision}, tau=0.6, u_in={u_in:.8f}"
+                                   + (f" (BASELINE.json {cfg_name})" if cfg_name and args.re == 200.0 else " (not a BASELINE.json config)"),
                        "nx": nx, "ny": ny_total, "rows_per_gpu": local_ny, "decomposition": f"{world} row strip(s)",
-                       "halo": "none" if world == 1 else "RCCL send/recv of the 3 edge rows x 9 populations per face after every launch (side stream, overlapped)",
-                       "kernel": ctx.kernel_name(), "plan": ctx.plan()},
+                       "arithmetic": ("FMA-contracted collision, one reciprocal (as the reference's -ffast-math -mfma build permits; rho/u within "
+                                      "1e-10 of the reference)" if args.arith == "contracted" else
+                                      "strict IEEE, operation by operation (populations bit-identical to the CPU oracle)"),
+                       "halo": "none" if world == 1 else f"RCCL send/recv of {hr} edge rows x 9 populations per face (one contiguous message "
+                                                          f"of {hr * 9} sub-rows); schedule: {ctx.strip_schedule()}",
+                       "kernel": kernel, "plan": ctx.plan(), "build_id": lbm.build_id(),
+                       "runtime": {"rccl": versions["rccl"], "hip_runtime": versions["hip_runtime"], "hip_driver": versions["hip_driver"],
+                                   "torch_loaded": torch is not None}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": ctx.kernel_name(), "kernel_ms": round(kernel_ms, 5),
-                         "algorithmic_bytes_per_launch": launch_bytes,
-                         "iterations_per_launch": round(iterations / max(launches, 1), 4),
-                         "note": "achieved = algorithmic bytes (144 B per lattice update, fp64) / time; a launch that fuses several "
-                                 "iterations through LDS moves fewer HBM bytes than that (traffic = measured bytes per launch), so frac can exceed 1"},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "basis": basis,
+                         "kernel": kernel, "kernel_ms": round(kernel_ms, 5),
+                         "algorithmic_bytes_per_launch": launch_bytes, "iterations_per_launch": round(ipl, 4),
+                         "equiv_144B_gbs": round(equiv, 1), "equiv_144B_frac": round(equiv / HBM_PEAK_GBS, 4),
+                         "note": "frac = HBM bytes actually moved per launch / time / peak (<= 1). equiv_144B_* price every lattice update at "
+                                 "the unfused 144 B (72 B fp32): a launch that fuses d iterations through LDS moves ~1/d of that, so the "
+                                 "equivalent figure can exceed the peak; it is the number to compare with an unfused kernel's roofline"},
         }
+        if world > 1:
+            line["strips"] = {"nranks": world, "schedule": ctx.strip_schedule(),
+                              "ms_per_step_compute_only": round(compute_only_ms, 5),
+                              "ms_per_step_exchange_exposed": round(dt / args.steps * 1e3 - compute_only_ms, 5)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(nx, ny_total, u_in)
         print(json.dumps(line), flush=True)

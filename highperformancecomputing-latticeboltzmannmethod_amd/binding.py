@@ -74,12 +74,22 @@ def lib():
         L.lbm_kernel_name.argtypes = [vp]; L.lbm_kernel_name.restype = C.c_char_p
         L.lbm_plan.argtypes = [vp]; L.lbm_plan.restype = C.c_char_p
         L.lbm_build_id.restype = C.c_char_p
+        L.lbm_runtime_versions.argtypes = [C.POINTER(C.c_int)] * 3
+        L.lbm_strip_schedule.argtypes = [vp]; L.lbm_strip_schedule.restype = C.c_char_p
         _lib = L
     return _lib
 
 
 def device_count():
     return lib().lbm_device_count()
+
+
+def runtime_versions():
+    """{'rccl': .., 'hip_runtime': .., 'hip_driver': ..} as bound by THIS process (ncclGetVersion etc.)."""
+    r, h, d = C.c_int(), C.c_int(), C.c_int()
+    if lib().lbm_runtime_versions(C.byref(r), C.byref(h), C.byref(d)) < 0:
+        raise LbmError(lib().lbm_last_error().decode())
+    return {"rccl": r.value, "hip_runtime": h.value, "hip_driver": d.value}
 
 
 def build_id():
@@ -238,6 +248,9 @@ class Context:
         v = C.c_double()
         self._chk(self.L.lbm_last_step_kernel_ms(self.h, C.byref(v)))
         return v.value
+
+    def strip_schedule(self):
+        return self.L.lbm_strip_schedule(self.h).decode()
 
     def kernel_name(self):
         return self.L.lbm_kernel_name(self.h).decode()

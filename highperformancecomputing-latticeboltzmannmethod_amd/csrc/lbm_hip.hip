@@ -96,6 +96,9 @@ struct lbm_ctx {
     char plan_desc[160] = "";
     int timing = 0;
     int overlap = 1;
+    bool overlap_pinned = false, deep_pinned = false;   // set through lbm_set_option: the strip tuner leaves them alone
+    int skip_exchange = 0;   // DIAGNOSTIC: issue every launch but no halo traffic (times the compute side of a strip run; results invalid)
+    char sched_desc[96] = "";
     int timed_launches = 0, timed_steps = 0;
     long launches_total = 0;
     // communicator
@@ -322,6 +325,7 @@ inline FaceSpans face_spans(const lbm_ctx* c) {
 // Transports of ONE context: RCCL send/recv between processes (rank r <-> r-1, r+1), or the test-only loopbacks.
 template <typename T>
 int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
+    if (c->skip_exchange) return LBM_OK;
     const FaceSpans f = face_spans(c);
     T* b = static_cast<T*>(c->buf[dst]);
     const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
@@ -366,7 +370,7 @@ inline hipStream_t exchange_stream(const lbm_ctx* c) { return c->overlap ? c->co
 //   rccl : all members' ncclSend/ncclRecv inside ONE ncclGroupStart/End (one communicator per member, ncclCommInitAll).
 template <typename T>
 int exchange_group(lbm_ctx** cs, int n, int dst) {
-    if (n < 2) return LBM_OK;
+    if (n < 2 || cs[0]->skip_exchange) return LBM_OK;
     if (cs[0]->group_transport == 1) {
         const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
         NCCLCHK(ncclGroupStart());
@@ -661,7 +665,7 @@ int time_plan(lbm_ctx* c, float* ms_out) {
 
 template <typename T>
 int choose_plan(lbm_ctx* c) {
-    const bool strips = (c->comm && c->nranks > 1) || c->group_n > 1;
+    const bool strips = (c->comm && c->nranks > 1) || c->group_n > 1 || c->loopback;
     const Plan fixed = {(strips || c->loopback) ? 1 : c->layout, c->variant, c->use_nt, c->alternate, c->fuse, c->pair_ty, c->xcd,
                         "fixed by options", c->slide};
     std::vector<Plan> cand;
@@ -747,6 +751,61 @@ int choose_plan(lbm_ctx* c) {
     return LBM_OK;
 }
 
+template <typename T> int do_steps(lbm_ctx** cs, int n, int nsteps, int of);
+int allreduce_doubles(lbm_ctx* c, double* vals, int n, int op);
+
+// Strip schedule by measurement (one rank of a multi-process run; collective: every rank runs the same trials and sees
+// the same reduced timings, so all ranks choose alike). The four schedules — exchange overlapped with the interior rows
+// or serialised, one exchange per two launches (deep halo) or per launch — compute identical results; which is fastest
+// depends on the strip height and on the link (overlap costs two extra launches and three events per group, which a
+// short strip cannot hide). 6 warm-up + 24 timed iterations each with the real transport, MAX over the ranks.
+template <typename T>
+int tune_strip_schedule(lbm_ctx* c) {
+    const bool multi = c->comm && (c->nranks > 1 || c->loopback == 2);
+    snprintf(c->sched_desc, sizeof(c->sched_desc), "overlap=%d deep_halo=%d (%s)", c->overlap, c->deep_halo,
+             multi ? "fixed by options" : "default");
+    if (!multi || !c->tune || (c->overlap_pinned && c->deep_pinned) || c->nyl < 4 * GR) return LBM_OK;
+    const int keep_overlap = c->overlap, keep_deep = c->deep_halo, keep_tp = c->trailing_pair;
+    double best_ms = 1e30;
+    int best_o = keep_overlap, best_d = keep_deep, tried = 0;
+    c->trailing_pair = 1;
+    for (int v = 0; v < 4; ++v) {
+        const int o = v & 1 ? 0 : 1, d = v & 2 ? 0 : 1;
+        if ((c->overlap_pinned && o != keep_overlap) || (c->deep_pinned && d != keep_deep)) continue;
+        c->overlap = o; c->deep_halo = d;
+        int rc = do_steps<T>(&c, 1, 6, 0);
+        if (rc) return rc;
+        rc = join_comm(c);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev_t0, c->stream));
+        rc = do_steps<T>(&c, 1, 24, 0);
+        if (rc) return rc;
+        rc = join_comm(c);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev_t1, c->stream));
+        HIPCHK(hipEventSynchronize(c->ev_t1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+        double worst = (double)ms;
+        rc = allreduce_doubles(c, &worst, 1, 1);       // MAX over the ranks: the job advances at the pace of its slowest strip
+        if (rc) return rc;
+        ++tried;
+        if (worst < best_ms) { best_ms = worst; best_o = o; best_d = d; }
+    }
+    c->overlap = best_o; c->deep_halo = best_d; c->trailing_pair = keep_tp;
+    snprintf(c->sched_desc, sizeof(c->sched_desc), "overlap=%d deep_halo=%d (fastest of %d measured, %.2f us/iteration)", best_o,
+             best_d, tried, best_ms * 1e3 / 24.0);
+    // back to iteration 0 with fresh halos
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->comm_stream));
+    c->mid_pair = false; c->comm_issued = false; c->launches_total = 0; c->last_was_pair = false;
+    const int big = INT_MAX;
+    HIPCHK(hipMemcpyAsync(c->d_unstable, &big, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    int rc = init_state<T>(c);
+    if (rc) return rc;
+    return exchange_rccl<T>(c, c->cur, c->stream);
+}
+
 template <typename T>
 int do_initialise(lbm_ctx* c) {
     int rc = choose_plan<T>(c);
@@ -757,6 +816,8 @@ int do_initialise(lbm_ctx* c) {
     if (rc) return rc;
     if ((c->comm || c->loopback) && c->group_n <= 1) {   // (a group exchanges once all members are initialised)
         rc = exchange_rccl<T>(c, c->cur, c->stream);
+        if (rc) return rc;
+        rc = tune_strip_schedule<T>(c);
         if (rc) return rc;
     }
     return LBM_OK;
@@ -960,6 +1021,17 @@ int do_set_f_current(lbm_ctx* c, const double* aos) {
 
 #define DISPATCH(c, call_d, call_f) ((c)->p.precision == LBM_PRECISION_F32 ? (call_f) : (call_d))
 
+}  // namespace
+
+namespace {
+int allreduce_doubles(lbm_ctx* c, double* vals, int n, int op) {
+    HIPCHK(hipMemcpyAsync(c->d_red, vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const ncclRedOp_t rop = op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin);
+    NCCLCHK(ncclAllReduce(c->d_red, c->d_red, n, ncclDouble, rop, c->comm, c->stream));
+    HIPCHK(hipMemcpyAsync(vals, c->d_red, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LBM_OK;
+}
 }  // namespace
 
 // ---- checkpoint / restart (the reference keeps its state in memory only) ------------------------
@@ -1291,13 +1363,18 @@ int lbm_comm_allreduce(lbm_ctx* c, double* vals, int n, int op) {
     if (!c || !vals || n < 1 || n > 64) return fail(LBM_ERR_ARG, "bad argument");
     if (!c->comm) return (c->nranks == 1) ? LBM_OK : fail(LBM_ERR_COMM, "no communicator");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(c->d_red, vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    const ncclRedOp_t rop = op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin);
-    NCCLCHK(ncclAllReduce(c->d_red, c->d_red, n, ncclDouble, rop, c->comm, c->stream));
-    HIPCHK(hipMemcpyAsync(vals, c->d_red, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    return allreduce_doubles(c, vals, n, op);
+}
+
+int lbm_runtime_versions(int* rccl, int* hip_runtime, int* hip_driver) {
+    int v = 0;
+    if (rccl) { NCCLCHK(ncclGetVersion(&v)); *rccl = v; }
+    if (hip_runtime) { HIPCHK(hipRuntimeGetVersion(&v)); *hip_runtime = v; }
+    if (hip_driver) { HIPCHK(hipDriverGetVersion(&v)); *hip_driver = v; }
     return LBM_OK;
 }
+
+const char* lbm_strip_schedule(const lbm_ctx* c) { return c ? c->sched_desc : ""; }
 
 // ---- in-process groups of strips ----------------------------------------------------------------------------
 namespace {
@@ -1472,11 +1549,12 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "xcd") c->xcd = (int)value ? 1 : 0;
     else if (k == "slide") c->slide = (int)value ? 1 : 0;
     else if (k == "arith") { if (value != 0 && value != 1) return fail(LBM_ERR_ARG, "arith must be 0 (strict) or 1 (contracted)"); c->arith = (int)value; }
-    else if (k == "deep_halo") c->deep_halo = (int)value ? 1 : 0;
+    else if (k == "deep_halo") { c->deep_halo = (int)value ? 1 : 0; c->deep_pinned = true; }
+    else if (k == "skip_exchange") c->skip_exchange = (int)value ? 1 : 0;
     else if (k == "loopback") c->loopback = (int)value;   // 0 off, 1 device copies, 2 RCCL self send/recv
     else if (k == "pair_ty") { if (value != 8 && value != 12) return fail(LBM_ERR_ARG, "pair_ty must be 8 or 12"); c->pair_ty = (int)value; }
     else if (k == "tune") c->tune = (int)value ? 1 : 0;
-    else if (k == "overlap") c->overlap = (int)value;
+    else if (k == "overlap") { c->overlap = (int)value ? 1 : 0; c->overlap_pinned = true; }
     else return fail(LBM_ERR_ARG, "unknown option %s", key);
     return LBM_OK;
 }

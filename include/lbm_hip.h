@@ -130,6 +130,12 @@ int  lbm_group_link(lbm_ctx** ctxs, int n, int transport);
 int  lbm_group_initialise(lbm_ctx** ctxs, int n, int* solid_total_out);
 int  lbm_group_step(lbm_ctx** ctxs, int n, int nsteps, int output_frequency);
 int  lbm_group_refresh_halos(lbm_ctx** ctxs, int n);
+/* What this process actually bound at run time (another library loaded first may have brought its own RCCL / HIP):
+ * ncclGetVersion, hipRuntimeGetVersion, hipDriverGetVersion. Any pointer may be NULL. */
+int  lbm_runtime_versions(int* rccl, int* hip_runtime, int* hip_driver);
+/* The exchange schedule of a strip with a communicator ("overlap=.. deep_halo=.. (..)"): measured at lbm_initialise
+ * over the four schedules (collective; MAX over the ranks) unless pinned with lbm_set_option. */
+const char* lbm_strip_schedule(const lbm_ctx* c);
 /* Host-staged path (the buffers the reference hands to MPI_Isend/Irecv, LBMGrid.h:255-276). Each face buffer is
  * [LBM_HALO_ROWS][9][nx] doubles: the LBM_HALO_ROWS (= 6) interior rows next to that face, bottom row first, all nine
  * populations (six rows: up to two launches of up to three fused iterations each may run between two exchanges, the
@@ -157,6 +163,11 @@ int  lbm_load_state(lbm_ctx* c, const char* path);
  *                 "fuse" 1|2|3 iterations fused per launch through LDS (k_step2_tile / k_step3_tile;
  *                 "pair" 1 == "fuse" 2), "pair_ty" 8|12 tile height, "xcd" XCD-aware tile walk,
  *                 "trailing_pair" 1 lets an lbm_step call end on a fused launch (snapshots then need one more step)
+ *                 "slide" 1 the sliding-window fused kernel (k_step_slide) instead of the 2-D tile kernels,
+ *                 "arith" 0 strict IEEE collision (bit-identical to the CPU oracle) | 1 FMA-contracted (<= 1e-10)
+ *   strips:       "overlap" 1|0 exchange overlapped with the interior rows, "deep_halo" 1|0 one exchange per two
+ *                 launches (both measured at lbm_initialise when a communicator is attached, unless set here),
+ *                 "skip_exchange" 1 (diagnostic: no halo traffic, results invalid)
  *   "timing" 1    record HIP events around each lbm_step call (lbm_last_step_kernel_ms). */
 int  lbm_set_option(lbm_ctx* c, const char* key, long value);
 /* Average device time per step-kernel launch (ms) measured with HIP events on the context's stream around
