@@ -235,8 +235,11 @@ void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream
     }
     const int ty = c->pair_ty;
     dim3 grid((c->nx + 63) / 64, (a.y_cnt + ty - 1) / ty + (a.y_cnt2 + ty - 1) / ty);
-#define LBM_K2(TY_, NTH_, NT_, X_) hipLaunchKernelGGL((k_step2_tile<T, TY_, NTH_, NT_, X_>), grid, dim3(NTH_), 0, s, a, e)
-#define LBM_K3(TY_, NTH_, NT_, X_) hipLaunchKernelGGL((k_step3_tile<T, TY_, NTH_, NT_, X_>), grid, dim3(NTH_), 0, s, a, e)
+#define LBM_K2(TY_, NTH_, NT_, X_) do { if (fast) hipLaunchKernelGGL((k_step2_tile<T, TY_, NTH_, NT_, X_, AR_CONTRACTED>), grid, dim3(NTH_), 0, s, a, e); \
+                                         else hipLaunchKernelGGL((k_step2_tile<T, TY_, NTH_, NT_, X_, AR_STRICT>), grid, dim3(NTH_), 0, s, a, e); } while (0)
+#define LBM_K3(TY_, NTH_, NT_, X_) do { if (fast) hipLaunchKernelGGL((k_step3_tile<T, TY_, NTH_, NT_, X_, AR_CONTRACTED>), grid, dim3(NTH_), 0, s, a, e); \
+                                         else hipLaunchKernelGGL((k_step3_tile<T, TY_, NTH_, NT_, X_, AR_STRICT>), grid, dim3(NTH_), 0, s, a, e); } while (0)
+    const bool fast = c->arith == AR_CONTRACTED;
     const int sel = (ty == 12 ? 4 : 0) + (c->use_nt ? 2 : 0) + (c->xcd ? 1 : 0);
     if (depth == 3) {
         switch (sel) {
@@ -630,10 +633,8 @@ inline void apply_plan(lbm_ctx* c, const Plan& pl) {
     c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate; c->fuse = pl.fuse > 0 ? pl.fuse : 1; c->xcd = pl.xcd;
     if (pl.ty) c->pair_ty = pl.ty;
     c->slide = pl.slide;
-    if (c->arith == AR_CONTRACTED && c->fuse > 1) c->slide = 1;   // the tile kernels exist in strict arithmetic only
     if (c->slide && c->total * c->esize >= (size_t(1) << 32)) {   // k_step_slide addresses a buffer with 32-bit byte offsets
         c->slide = 0;
-        if (c->arith == AR_CONTRACTED) c->fuse = 1;
     }
 }
 
@@ -711,12 +712,6 @@ int choose_plan(lbm_ctx* c) {
             if (vec_ok) cand.push_back({0, 0, 0, 1, 1, 0, 0, "planar/vec16B/alternate"});
             cand.push_back({0, 1, 0, 1, 1, 0, 0, "planar/site/alternate"});
         }
-    }
-    if (c->arith == AR_CONTRACTED && cand.size() > 1) {   // the tile kernels exist in strict arithmetic only
-        std::vector<Plan> keep;
-        for (const Plan& pl : cand)
-            if (pl.fuse <= 1 || pl.slide) keep.push_back(pl);
-        cand.swap(keep);
     }
     free_buffers(c);                                // a second lbm_initialise starts from no population buffers
     void* best_buf[2] = {nullptr, nullptr};
@@ -1590,10 +1585,11 @@ const char* lbm_kernel_name(const lbm_ctx* c) {
     static thread_local char name[96];
     const char* t = c->p.precision == LBM_PRECISION_F32 ? "float" : "double";
     const char* nt = c->use_nt ? "true" : "false";
-    if (c->fuse > 1 && c->slide) snprintf(name, sizeof(name), "k_step_slide<%s,%d,6,%s>", t, c->fuse, nt);
-    else if (c->fuse > 1 && pair_possible(c)) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%s,%s>", c->fuse, t, c->pair_ty, c->pair_ty == 12 ? 768 : 512, nt, c->xcd ? "true" : "false");
-    else if (use_vec(c)) snprintf(name, sizeof(name), "k_step_vec<%s,%d,0,%s>", t, (int)(16 / c->esize), nt);
-    else snprintf(name, sizeof(name), "k_step_site<%s,0,%s>", t, nt);
+    const int ar = c->arith;
+    if (c->fuse > 1 && c->slide) snprintf(name, sizeof(name), "k_step_slide<%s,%d,6,%s,%d>", t, c->fuse, nt, ar);
+    else if (c->fuse > 1) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%s,%s,%d>", c->fuse, t, c->pair_ty, c->pair_ty == 12 ? 768 : 512, nt, c->xcd ? "true" : "false", ar);
+    else if (use_vec(c)) snprintf(name, sizeof(name), "k_step_vec<%s,%d,0,%s,%d>", t, (int)(16 / c->esize), nt, ar);
+    else snprintf(name, sizeof(name), "k_step_site<%s,0,%s,%d>", t, nt, ar);
     return name;
 }
 

@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
 // value would pin 18 scalar registers for the whole kernel (the fused kernels are SGPR-bound).
 template <typename T> struct K2Extra { const T* feq_in; };
 
-template <typename T, int TY, int NTH, bool NT, bool XCD = false>
+template <typename T, int TY, int NTH, bool NT, bool XCD = false, int AR = AR_STRICT>
 __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int TX = 64, RW = TX + 2, RH = TY + 2, LP = RW + 2;
     __shared__ T lds[Q][RH][LP];
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
             T rho_bc, u_out;
             if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
             bad |= any_unstable(f);
-            bgk_collide(f, a.tau_inv);
+            bgk_collide<T, AR>(f, a.tau_inv);
             if (near_cyl) {                    // solid cells keep w_i (the collision result of such a cell is discarded)
 #pragma unroll
                 for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
         if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
         bad |= any_unstable(f);
         if (solid) continue;
-        bgk_collide(f, a.tau_inv);
+        bgk_collide<T, AR>(f, a.tau_inv);
         const long c = (long)(y + GR) * a.pitch + a.xoff + x;
 #pragma unroll
         for (int i = 0; i < Q; ++i) {
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
 //   phase 3  the tile: pull P_{t+2} from LDS, BCs, collide, store P_{t+3}.
 // HBM traffic per update ~ (1 + (TX+4)(TY+4)/(TX TY)) * 24 B (58 B at 64x12); redundant collisions 1.21x. Bit-identical to
 // three single launches (tests). Rows of neighbouring strips must be present three deep beyond the rows written.
-template <typename T, int TY, int NTH, bool NT, bool XCD>
+template <typename T, int TY, int NTH, bool NT, bool XCD, int AR = AR_STRICT>
 __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int TX = 64, R1W = TX + 4, R1H = TY + 4, R2W = TX + 2, R2H = TY + 2, LP = R1W;
     static_assert(R2W * R2H <= 2 * NTH, "two region-2 cells per thread at most");
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
             T rho_bc, u_out;
             if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
             bad |= any_unstable(f);
-            bgk_collide(f, a.tau_inv);
+            bgk_collide<T, AR>(f, a.tau_inv);
             if (near_cyl) {                    // solid cells keep w_i (the collision result of such a cell is discarded)
 #pragma unroll
                 for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
             T rho_bc, u_out;
             if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
             if (y <= y_end) bad |= any_unstable(f);
-            bgk_collide(f, a.tau_inv);
+            bgk_collide<T, AR>(f, a.tau_inv);
             if (near_cyl) {                    // solid cells keep w_i (the collision result of such a cell is discarded)
 #pragma unroll
                 for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
         if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
         bad |= any_unstable(f);
         if (solid) continue;
-        bgk_collide(f, a.tau_inv);
+        bgk_collide<T, AR>(f, a.tau_inv);
         const long c = (long)(y + GR) * a.pitch + a.xoff + x;
 #pragma unroll
         for (int i = 0; i < Q; ++i) {

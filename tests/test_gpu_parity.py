@@ -50,6 +50,8 @@ PLANS = {
     "fast-vec-alt": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=1, arith=1),
     "fast-slide3-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=3, slide=1, arith=1),
     "fast-rowil-slide2": dict(tune=0, layout=1, variant=1, nt=0, alternate=0, fuse=2, slide=1, arith=1),
+    "fast-rowil-fuse3-12-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
+    "fast-planar-pair8": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, pair=1, pair_ty=8, arith=1),
 }
 FAST = [k for k, v in PLANS.items() if v and v.get("arith")]
 
@@ -203,7 +205,7 @@ def test_contracted_arithmetic_is_plan_independent(lbm):
     nx, ny, steps, of = 320, 90, 240, 60
     kw = dict(inlet_velocity=0.07, cylinder_radius=0.1)
     out = []
-    for plan in ("fast-site", "fast-vec-alt", "fast-slide3-nt", "fast-rowil-slide2"):
+    for plan in ("fast-site", "fast-vec-alt", "fast-slide3-nt", "fast-rowil-slide2", "fast-rowil-fuse3-12-xcd", "fast-planar-pair8"):
         with lbm.Context(nx, ny, options=PLANS[plan], **kw) as ctx:
             ctx.initialise()
             ctx.step(steps, of)
@@ -571,6 +573,76 @@ def test_fp32_variant_tracks_fp64(lbm):
     for other in ("f32b", "f32c", "f32d", "f32e"):       # every fp32 formulation is the same arithmetic: bit-identical
         for a, b in zip(out["f32"], out[other]):
             assert np.array_equal(a, b)
+
+
+def test_fp32_tracks_fp64_on_fused_plans_1024x256(lbm):
+    """fp32 parity where the fused kernels and the measured plan are in play: BASELINE.json configs[1] grid (1024x256,
+    Re=100), 1000 iterations. The reference has no fp32 path, so the yardstick is the fp64 result of this library
+    (itself pinned to the oracle / the reference). Stated tolerance: 1e-3 relative on rho and on u (L-inf / L-inf, u
+    relative to max|u|); measured on MI355X: see DESIGN.md §4. Every fp32 plan must agree with every other bit for bit."""
+    nx, ny, steps = 1024, 256, 1000
+    kw = dict(inlet_velocity=0.13020833)
+    with lbm.Context(nx, ny, precision="f64", **kw) as ctx:
+        ctx.initialise()
+        ctx.step(steps, 0)
+        ref = ctx.macros()
+    out = {}
+    for plan in ("auto", "rowil-fuse3-12-nt-xcd", "planar-slide3-nt", "rowil-slide2-nt", "planar-site"):
+        with lbm.Context(nx, ny, precision="f32", options=PLANS[plan], **kw) as ctx:
+            ctx.initialise()
+            ctx.step(steps, 0)
+            assert ctx.first_unstable_step() == -1
+            out[plan] = ctx.macros()
+    er, eu = macro_errors(*out["auto"], *ref)
+    print(f"fp32 vs fp64, 1024x256 x {steps}: rho {er:.3e}, u {eu:.3e}")
+    assert er < 1e-3 and eu < 1e-3, (er, eu)
+    for plan, m in out.items():
+        for a, b in zip(out["auto"], m):
+            assert np.array_equal(a, b), plan
+    with lbm.Context(nx, ny, precision="f32", options=PLANS["fast-auto"], **kw) as ctx:      # contracted fp32
+        ctx.initialise()
+        ctx.step(steps, 0)
+        er, eu = macro_errors(*ctx.macros(), *ref)
+        print(f"fp32 contracted vs fp64: rho {er:.3e}, u {eu:.3e}")
+        assert er < 1e-3 and eu < 1e-3, (er, eu)
+
+
+def test_c5_grid_16384x4096_fp32_single_gpu(lbm):
+    """BASELINE.json configs[4] workload (16384x4096 fp32, Re=200) on ONE GPU (2.4 GB per population buffer; the 8-GPU
+    strip run belongs to the driver), with the measured plan. The reference has no fp32 path and a CPU oracle run of 67 M
+    cells is out of reach, so at full size the checks are the size-independent properties: geometry (130 721 solid
+    cells), stability over 300 iterations, physical sanity of the fields, run-to-run determinism,
+    plan-to-plan bit-equality (measured plan vs tile kernel vs sliding kernel vs one launch per iteration) and
+    decomposition invariance (8 in-process strips with the production exchange choreography == the whole domain)."""
+    nx, ny, steps = 16384, 4096, 300
+    kw = dict(inlet_velocity=0.01627604, precision="f32")
+
+    def run(options):
+        with lbm.Context(nx, ny, options=options, **kw) as ctx:
+            assert ctx.initialise() == 130721
+            ctx.step(steps, 150)
+            assert ctx.first_unstable_step() == -1
+            return ctx.macros(), ctx.drain_force_log(), ctx.plan(), ctx.kernel_name()
+    (rho, ux, uy), log, plan, kernel = run(None)
+    print("C5 plan:", plan, "|", kernel)
+    assert np.isfinite(rho).all() and 0.9 < rho.min() and rho.max() < 1.1
+    assert abs(float(ux[ny // 4, nx // 2]) - 0.01627604) < 2e-3 and float(np.abs(uy).max()) < 0.1
+    assert [r[0] for r in log] == [0, 150]
+    for options in (None, PLANS["rowil-fuse3-12-nt-xcd"], PLANS["planar-slide3-nt"], PLANS["rowil-site-nt"]):
+        m2, log2, _, _ = run(options)
+        for a, b in zip((rho, ux, uy), m2):
+            assert np.array_equal(a, b), options
+        assert log2 == log
+        del m2
+    with lbm.Group(nx, ny, 8, options=dict(PLANS["rowil-slide3"]), **kw) as g:
+        assert g.initialise() == 130721
+        g.step(steps, 150)
+        assert g.first_unstable_step() == -1
+        for a, b in zip((rho, ux, uy), g.macros()):
+            assert np.array_equal(a, b)
+        glog = g.drain_force_log()
+    for (t, fx, fy), (t2, gx, gy) in zip(log, glog):
+        assert t == t2 and abs(fx - gx) <= 1e-6 * max(1.0, abs(fx)) and abs(fy - gy) <= 1e-6
 
 
 def test_full_size_4096x1024_properties(lbm):
