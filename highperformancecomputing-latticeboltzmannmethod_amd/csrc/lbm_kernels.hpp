@@ -20,11 +20,16 @@
 // are refreshed every step by the halo exchange. The step kernel therefore needs no boundary branches for
 // its nine pulls and writes fluid interior cells only.
 //
-// Kernel families (all evaluate the SAME per-cell operation sequence => bit-identical results):
-//   k_step_site / k_step_vec   one iteration per launch, 144 B of HBM traffic per lattice update (fp64)
-//   k_step2_tile / k_step3_tile two / three iterations per launch, intermediate states in LDS: 84 / 60 B per update
-//                               measured (production path: 89-93 GLUPS at 4096x1024 fp64 on one MI355X)
+// Kernel families (within one arithmetic mode all evaluate the SAME per-cell operation sequence => bit-identical results):
+//   k_step_site / k_step_vec     one iteration per launch, 144 B of HBM traffic per lattice update (fp64)
+//   k_step2_tile / k_step3_tile  two / three iterations per launch over 64 x TY tiles, intermediate states in LDS:
+//                                84 / 50-60 B per update measured (production path: 93-95 GLUPS strict, 100-104 GLUPS
+//                                contracted at 4096x1024 fp64 on one MI355X)
+//   k_step_slide                 two / three iterations per launch, 64-wide column blocks marching in y over LDS rings
+//                                (no y re-reads: 49 B per update; tuner candidate)
 //   k_init, k_macros, k_forces, k_halo_pack/unpack   set-up and the output cadence
+// Arithmetic modes of the collision (enum Arith): strict IEEE operation by operation (bit-identical to the CPU oracle)
+// or FMA-contracted with one reciprocal (what the reference's -ffast-math -mfma build permits; <= 1e-10).
 //
 // Step kernel K_t (one iteration = one loop body of Solver::run, LBMSolver.h:49-60):
 //     pull from P_t        == exchange_ghost_cells + streaming_step        (LBMGrid.h:249, LBMSolver.h:128-145)

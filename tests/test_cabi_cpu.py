@@ -38,6 +38,13 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, s), f"liblbm_hip.so does not export {s}"
 
 
+def test_library_carries_the_hash_of_its_sources(pkg):
+    """build() ties the binary to the tree: the id embedded in the .so (readable without dlopen) == SHA-256 of csrc/* and
+    include/lbm_hip.h == what lbm_build_id() returns; a stale .so is rebuilt (build.py)."""
+    assert re.fullmatch(r"[0-9a-f]{16}", pkg.source_id())
+    assert pkg.embedded_id() == pkg.source_id() == pkg.build_id()
+
+
 def test_no_cpu_fallback(pkg):
     """Without a HIP device lbm_create must fail with LBM_ERR_HIP; with one this test is vacuous."""
     if pkg.device_count() > 0:
