@@ -14,8 +14,9 @@ measured at initialise). Populations are resident in HBM before the timed region
 it and no output (forces/VTK) step falls inside it.
 
 Runtime hygiene: liblbm_hip.so is loaded BEFORE torch (and torch only at N>1, for the gloo rendezvous of the 128-byte
-ncclUniqueId and the barriers), so that the process binds the ROCm RCCL/HIP the library was built and tested against,
-not the copies bundled with the torch wheel; the versions actually bound are printed in the JSON line.
+ncclUniqueId and the barriers; no torch.cuda call is made), so that the process binds the ROCm RCCL/HIP the library was
+built and tested against, not the copies bundled with the torch wheel; the versions actually bound are printed in the
+JSON line. The timed region is bracketed by lbm_sync (both streams of the library) + a gloo barrier on both sides.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (live HIP-event kernel time on the
 library's own stream; `frac` = measured HBM bytes per launch / time / 8 TB/s, the 144 B-per-update figure separately) and,
@@ -182,9 +183,10 @@ def main():
     ctx.set_option("timing", 1)
 
     def fence():
-        ctx.sync()                       # both streams of the library (every kernel and every exchange lives on them)
-        if torch is not None and torch.cuda.is_available():
-            torch.cuda.synchronize()
+        # Device side: lbm_sync drains both streams of the library — every kernel and every exchange of this process lives
+        # on them. (torch.cuda.synchronize() is not an option here: with the ROCm runtime of the library resident, the torch
+        # wheel's own HIP initialisation finds no device — torch is used for the gloo rendezvous and barriers only.)
+        ctx.sync()
         if world > 1:
             dist.barrier()
 
