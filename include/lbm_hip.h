@@ -165,8 +165,10 @@ int  lbm_load_state(lbm_ctx* c, const char* path);
  *                 "trailing_pair" 1 lets an lbm_step call end on a fused launch (snapshots then need one more step)
  *                 "slide" 1 the sliding-window fused kernel (k_step_slide) instead of the 2-D tile kernels,
  *                 "arith" 0 strict IEEE collision (bit-identical to the CPU oracle) | 1 FMA-contracted (<= 1e-10)
- *   strips:       "overlap" 1|0 exchange overlapped with the interior rows, "deep_halo" 1|0 one exchange per two
- *                 launches (both measured at lbm_initialise when a communicator is attached, unless set here),
+ *   strips:       "overlap" 0 launch and exchange serialised | 1 edge bands first, the exchange overlapped with the interior
+ *                 rows of the SAME launch | 2 the exchange overlapped with the interior rows of the NEXT (extended)
+ *                 launch; "deep_halo" 1|0 one exchange per two launches (both measured at lbm_initialise when a
+ *                 communicator is attached, unless set here),
  *                 "skip_exchange" 1 (diagnostic: no halo traffic, results invalid)
  *   "timing" 1    record HIP events around each lbm_step call (lbm_last_step_kernel_ms). */
 int  lbm_set_option(lbm_ctx* c, const char* key, long value);

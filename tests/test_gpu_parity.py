@@ -329,7 +329,7 @@ def test_overlap_choreography_with_loopback_halo(lbm, pair):
     kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
     out = []
     # deep_halo=0: one exchange after every launch; deep_halo=1: one per two launches (the first one extended)
-    for overlap, deep in ((0, 0), (0, 1), (1, 1), (1, 0)):
+    for overlap, deep in ((0, 0), (0, 1), (1, 1), (1, 0), (2, 1), (2, 0)):
         with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, fuse=pair, pair_ty=12, xcd=1,
                                               loopback=1, overlap=overlap, deep_halo=deep), **kw) as ctx:
             ctx.initialise()
@@ -341,7 +341,7 @@ def test_overlap_choreography_with_loopback_halo(lbm, pair):
         assert out[0][1] == other[1] and out[0][2] == other[2]
 
 
-@pytest.mark.parametrize("overlap,deep", [(1, 1), (0, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("overlap,deep", [(1, 1), (0, 1), (1, 0), (0, 0), (2, 1), (2, 0)])
 @pytest.mark.parametrize("plan", ["rowil-fuse3-12-nt-xcd", "rowil-slide3", "rowil-site-nt", "fast-rowil-slide2"])
 def test_group_of_strips_on_one_device_matches_single_domain_bitwise(lbm, plan, overlap, deep):
     """In-process strips (lbm_group_*, the transport `lbm_solver --gpus N` uses) with the production choreography: edge
@@ -457,7 +457,7 @@ def test_rccl_calls_on_a_one_rank_communicator(lbm):
     nx, ny, steps = 1024, 96, 151
     kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
     out = []
-    for loopback, overlap in ((1, 0), (2, 1), (2, 0)):
+    for loopback, overlap in ((1, 0), (2, 1), (2, 0), (2, 2)):
         with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1,
                                               loopback=loopback, overlap=overlap), **kw) as ctx:
             if loopback == 2:

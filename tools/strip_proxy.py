@@ -15,16 +15,20 @@ nx, ny = 4096, 1024
 for n in (1, 2, 4, 8):
     rows = ny // n
     line = [f"N={n} rows={rows}:"]
-    for name, opts in (("no-exchange", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1)),
-                       ("loopback overlap", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, loopback=1, overlap=1)),
-                       ("loopback serial", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, loopback=1, overlap=0)),
-                       ("rccl-self overlap", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, loopback=2, overlap=1)),
-                       ("rccl-self serial", dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, loopback=2, overlap=0))):
+    base = dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, arith=1, trailing_pair=1)
+    for name, opts in (("no-exchange", dict(base)),
+                       ("rccl-self TUNED", dict(arith=1, trailing_pair=1, loopback=2)),
+                       ("rccl-self ovl+deep", dict(base, loopback=2, overlap=1, deep_halo=1)),
+                       ("rccl-self ser+deep", dict(base, loopback=2, overlap=0, deep_halo=1)),
+                       ("rccl-self next+deep", dict(base, loopback=2, overlap=2, deep_halo=1)),
+                       ("rccl-self ser+shallow", dict(base, loopback=2, overlap=0, deep_halo=0)),
+                       ):
         with lbm.Context(nx, rows, inlet_velocity=0.05, options=opts) as c:
             if opts.get("loopback") == 2:
                 c.comm_init(0, 1, c.comm_unique_id())      # one-rank communicator: ncclSend/ncclRecv to self
             c.initialise()
             c.step(300, 0); c.sync()
             t0 = time.perf_counter(); c.step(3000, 0); c.sync(); dt = time.perf_counter() - t0
-            line.append(f"{name} {dt / 3000 * 1e6:.2f} us/it ({nx * rows * 3000 / dt / 1e6 * n:.0f} MLUPS x{n} ranks)")
+            extra = f" [{c.strip_schedule()} | {c.kernel_name()}]" if "TUNED" in name else ""
+            line.append(f"{name} {dt / 3000 * 1e6:.2f} us/it ({nx * rows * 3000 / dt / 1e6 * n:.0f} MLUPS x{n} ranks){extra}")
     print("  ".join(line), flush=True)
