@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(HERE, "csrc", "liblbm_hip.so")
+_LIB_PATH = os.environ.get("LBM_HIP_LIBRARY") or os.path.join(HERE, "csrc", "liblbm_hip.so")   # (override: diagnostic builds)
 
 
 class LbmError(RuntimeError):
