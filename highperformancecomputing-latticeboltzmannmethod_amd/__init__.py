@@ -6,6 +6,6 @@ into csrc/liblbm_hip.so) and host/ (the C++20 mirror of the reference's Solver/G
 This Python package is a thin ctypes view of the same C-ABI used by tests/ and bench.py; it contains no
 numerics of its own and fails loudly if the HIP library is missing.
 """
-from .binding import (LbmError, Params, Context, Group, lib, lib_path, device_count, build_id, runtime_versions)  # noqa: F401
+from .binding import (LbmError, Params, Context, Group, lib, lib_path, device_count, build_id, runtime_versions, device_memory)  # noqa: F401
 from .build import build_all, source_id, embedded_id  # noqa: F401
 from .strips import partition_rows, GlooHalo  # noqa: F401

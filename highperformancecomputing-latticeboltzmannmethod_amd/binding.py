@@ -76,6 +76,7 @@ def lib():
         L.lbm_build_id.restype = C.c_char_p
         L.lbm_runtime_versions.argtypes = [C.POINTER(C.c_int)] * 3
         L.lbm_strip_schedule.argtypes = [vp]; L.lbm_strip_schedule.restype = C.c_char_p
+        L.lbm_device_memory.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
         _lib = L
     return _lib
 
@@ -90,6 +91,14 @@ def runtime_versions():
     if lib().lbm_runtime_versions(C.byref(r), C.byref(h), C.byref(d)) < 0:
         raise LbmError(lib().lbm_last_error().decode())
     return {"rccl": r.value, "hip_runtime": h.value, "hip_driver": d.value}
+
+
+def device_memory(device=0):
+    """(free, total) bytes of a device (hipMemGetInfo)."""
+    f, t = C.c_ulonglong(), C.c_ulonglong()
+    if lib().lbm_device_memory(device, C.byref(f), C.byref(t)) < 0:
+        raise LbmError(lib().lbm_last_error().decode())
+    return f.value, t.value
 
 
 def build_id():

@@ -1406,6 +1406,15 @@ int lbm_runtime_versions(int* rccl, int* hip_runtime, int* hip_driver) {
 
 const char* lbm_strip_schedule(const lbm_ctx* c) { return c ? c->sched_desc : ""; }
 
+int lbm_device_memory(int device, unsigned long long* free_bytes, unsigned long long* total_bytes) {
+    size_t f = 0, t = 0;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return LBM_OK;
+}
+
 // ---- in-process groups of strips ----------------------------------------------------------------------------
 namespace {
 int check_group(lbm_ctx** cs, int n, bool linked) {

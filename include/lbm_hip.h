@@ -133,6 +133,8 @@ int  lbm_group_refresh_halos(lbm_ctx** ctxs, int n);
 /* What this process actually bound at run time (another library loaded first may have brought its own RCCL / HIP):
  * ncclGetVersion, hipRuntimeGetVersion, hipDriverGetVersion. Any pointer may be NULL. */
 int  lbm_runtime_versions(int* rccl, int* hip_runtime, int* hip_driver);
+/* hipMemGetInfo of a device (leak checks; sizing of strips). Any pointer may be NULL. */
+int  lbm_device_memory(int device, unsigned long long* free_bytes, unsigned long long* total_bytes);
 /* The exchange schedule of a strip with a communicator ("overlap=.. deep_halo=.. (..)"): measured at lbm_initialise
  * over the four schedules (collective; MAX over the ranks) unless pinned with lbm_set_option. */
 const char* lbm_strip_schedule(const lbm_ctx* c);

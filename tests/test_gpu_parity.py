@@ -545,6 +545,30 @@ def test_strips_two_launches_per_exchange_match_single_domain_bitwise(lbm):
         c.close()
 
 
+def test_reinitialise_and_destroy_release_device_memory(lbm):
+    """A second lbm_initialise (new plan measurement, new buffers) must not keep the first one's population buffers, an
+    error path of the plan search must not either, and lbm_destroy returns everything (hipMemGetInfo)."""
+    nx, ny = 2048, 512
+    free0, _ = lbm.device_memory(0)
+    with lbm.Context(nx, ny, inlet_velocity=0.05) as ctx:
+        ctx.initialise()
+        ctx.step(10, 0)
+        ctx.macros()
+        ctx.sync()
+        free1, _ = lbm.device_memory(0)
+        for _ in range(3):
+            ctx.initialise()
+            ctx.step(10, 0)
+            ctx.macros()
+        ctx.sync()
+        free2, _ = lbm.device_memory(0)
+        assert abs(free1 - free2) <= 8 << 20, (free1, free2)      # (allocation granularity of differently laid-out plans)
+        used = free0 - free2
+        assert used < 3 * 2 * 9 * (nx + 32) * (ny + 12) * 8, used   # two buffers (+ scratch, macros), not 2 x (initialisations)
+    free3, _ = lbm.device_memory(0)
+    assert abs(free3 - free0) <= 8 << 20, (free0, free3)
+
+
 def test_snapshot_refused_after_trailing_pair(lbm):
     with lbm.Context(128, 32, options=dict(tune=0, fuse=3, trailing_pair=1)) as ctx:
         ctx.initialise()
