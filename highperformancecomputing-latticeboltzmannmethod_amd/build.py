@@ -49,7 +49,7 @@ def build_all(force=False, verbose=False):
         # -ffp-contract=off: no fused multiply-add is formed behind the source's back, so every formulation of the
         # step kernel (site / vector / fused, any layout) and the strict-IEEE oracle evaluate the same operation sequence
         tmp = LIB + ".tmp"
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", "-shared",
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
                "-DLBM_BUILD_ID_STR=\"" + want + "\"",
                "-o", tmp, os.path.join(CSRC, "lbm_hip.hip"),
                "-L" + os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib")]

@@ -11,8 +11,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <barrier>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace lbmk;
@@ -110,6 +114,7 @@ struct lbm_ctx {
     lbm_ctx* nb_south = nullptr;
     lbm_ctx* nb_north = nullptr;
     int group_transport = 0, group_n = 1, group_k = 0;
+    int group_threads = 1;   // a group is driven by one host thread per strip (0: the calling thread issues for every strip)
     bool owns_comm = true;
     int edge_rows[2] = {0, 0};   // edge-band heights of the launch in flight (issue_before -> issue_after)
     bool ext_split_pending = false;   // overlap 2: the edge part of the last extended launch is queued on the side stream (ev_edge)
@@ -372,6 +377,28 @@ inline hipStream_t exchange_stream(const lbm_ctx* c) { return c->overlap ? c->co
 //   peer : each strip PULLS its neighbours' edge rows into its own ghost rows (hipMemcpyPeerAsync over xGMI, a plain
 //          device copy when both strips share a device) on its own exchange stream, behind the neighbour's ev_edge;
 //   rccl : all members' ncclSend/ncclRecv inside ONE ncclGroupStart/End (one communicator per member, ncclCommInitAll).
+// peer transport, one member: pull the neighbours' edge rows of buf[dst] into my ghost rows on my exchange stream
+template <typename T>
+int pull_halos(lbm_ctx** cs, int n, int k, int dst) {
+    lbm_ctx* c = cs[k];
+    if (c->skip_exchange) return LBM_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const FaceSpans f = face_spans(c);
+    T* b = static_cast<T*>(c->buf[dst]);
+    hipStream_t s = exchange_stream(c);
+    const size_t bytes = f.cnt * sizeof(T);
+    auto pull = [&](lbm_ctx* nb, long nb_rows, long my_ghost) -> int {
+        const T* src = static_cast<const T*>(nb->buf[dst]) + nb_rows;
+        HIPCHK(hipStreamWaitEvent(s, nb->ev_edge, 0));            // the neighbour's edge rows of this launch are written
+        if (nb->device == c->device) HIPCHK(hipMemcpyAsync(b + my_ghost, src, bytes, hipMemcpyDeviceToDevice, s));
+        else HIPCHK(hipMemcpyPeerAsync(b + my_ghost, c->device, src, nb->device, bytes, s));
+        return LBM_OK;
+    };
+    if (k > 0) { int rc = pull(cs[k - 1], face_spans(cs[k - 1]).top_rows, f.ghost_s); if (rc) return rc; }
+    if (k + 1 < n) { int rc = pull(cs[k + 1], face_spans(cs[k + 1]).bot_rows, f.ghost_n); if (rc) return rc; }
+    return LBM_OK;
+}
+
 template <typename T>
 int exchange_group(lbm_ctx** cs, int n, int dst) {
     if (n < 2 || cs[0]->skip_exchange) return LBM_OK;
@@ -396,21 +423,8 @@ int exchange_group(lbm_ctx** cs, int n, int dst) {
         return LBM_OK;
     }
     for (int k = 0; k < n; ++k) {
-        lbm_ctx* c = cs[k];
-        HIPCHK(hipSetDevice(c->device));
-        const FaceSpans f = face_spans(c);
-        T* b = static_cast<T*>(c->buf[dst]);
-        hipStream_t s = exchange_stream(c);
-        const size_t bytes = f.cnt * sizeof(T);
-        auto pull = [&](lbm_ctx* nb, long nb_rows, long my_ghost) -> int {
-            const T* src = static_cast<const T*>(nb->buf[dst]) + nb_rows;
-            HIPCHK(hipStreamWaitEvent(s, nb->ev_edge, 0));            // the neighbour's edge rows of this launch are written
-            if (nb->device == c->device) HIPCHK(hipMemcpyAsync(b + my_ghost, src, bytes, hipMemcpyDeviceToDevice, s));
-            else HIPCHK(hipMemcpyPeerAsync(b + my_ghost, c->device, src, nb->device, bytes, s));
-            return LBM_OK;
-        };
-        if (k > 0) { int rc = pull(cs[k - 1], face_spans(cs[k - 1]).top_rows, f.ghost_s); if (rc) return rc; }
-        if (k + 1 < n) { int rc = pull(cs[k + 1], face_spans(cs[k + 1]).bot_rows, f.ghost_n); if (rc) return rc; }
+        int rc = pull_halos<T>(cs, n, k, dst);
+        if (rc) return rc;
     }
     return LBM_OK;
 }
@@ -867,6 +881,61 @@ int do_steps(lbm_ctx** cs, int n, int nsteps, int of) {
     const bool transport = n > 1 || (c0->comm && c0->nranks > 1) || c0->loopback;   // a device transport is attached
     int launches = 0;
     std::vector<Launch> L((size_t)n);
+    if (n > 1 && c0->group_threads) {
+        // One host thread per strip: a launch costs a strip ~10 runtime calls (kernels, events, copies), which one thread
+        // issuing for 8 GPUs in turn cannot hide behind 20 us kernels. Three rendezvous per launch: every strip's
+        // ev_edge is recorded before anybody pulls, every pull is queued before anybody records ev_comm / launches the
+        // interior, and every ev_comm is recorded before the next launch looks at its neighbours'.
+        std::barrier sync(n);
+        std::atomic<int> err{LBM_OK};
+        std::mutex mu;
+        std::string msg;
+        auto report = [&](int rc) {
+            if (rc == LBM_OK) return;
+            std::lock_guard<std::mutex> lk(mu);
+            if (err.load() == LBM_OK) { msg = g_err; err.store(rc); }
+        };
+        auto worker = [&](int i) {
+            lbm_ctx* c = cs[i];
+            (void)hipSetDevice(c->device);
+            for (int k = 0; k < nsteps;) {
+                const int t = c->steps_done;
+                int rc = LBM_OK;
+                if (of > 0 && t % of == 0) {
+                    if (c->log_count >= c->log_cap) rc = fail(LBM_ERR_ARG, "force log full (%d rows): drain it", c->log_cap);
+                    if (!rc) rc = join_comm(c);
+                    if (!rc) rc = launch_forces<T>(c, c->d_force_log + 3L * c->log_count, t);
+                    if (!rc) c->log_count++;
+                }
+                if (!rc) rc = plan_launch(c, nsteps - k, of, transport, true, &L[(size_t)i]);
+                if (!rc) rc = issue_before<T>(c, L[(size_t)i]);
+                report(rc);
+                sync.arrive_and_wait();
+                if (err.load() != LBM_OK) return;
+                if (L[(size_t)i].depth != L[0].depth || L[(size_t)i].kind != L[0].kind)
+                    report(fail(LBM_ERR_ARG, "the strips of a group disagree on the next launch (different options?)"));
+                else if (L[0].kind == KIND_EXCHANGE) {
+                    if (c0->group_transport == 0) report(pull_halos<T>(cs, n, i, L[0].dst));
+                    else if (i == 0) report(exchange_group<T>(cs, n, L[0].dst));      // RCCL: one group call, one thread
+                }
+                sync.arrive_and_wait();
+                if (err.load() != LBM_OK) return;
+                report(issue_after<T>(c, L[(size_t)i]));
+                sync.arrive_and_wait();
+                if (err.load() != LBM_OK) return;
+                k += L[(size_t)i].depth;       // (its own copy: strip 0 may already be planning the next launch into L[0])
+                if (i == 0) ++launches;
+            }
+        };
+        const int t_begin = c0->steps_done;
+        std::vector<std::thread> th;
+        for (int i = 1; i < n; ++i) th.emplace_back(worker, i);
+        worker(0);
+        for (auto& x : th) x.join();
+        if (err.load() != LBM_OK) return fail(err.load(), "%s", msg.c_str());
+        HIPCHK(hipSetDevice(c0->device));
+        (void)t_begin;
+    } else
     for (int k = 0; k < nsteps;) {
         const int t = c0->steps_done;
         for (int i = 0; i < n; ++i) {
@@ -1591,6 +1660,7 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "arith") { if (value != 0 && value != 1) return fail(LBM_ERR_ARG, "arith must be 0 (strict) or 1 (contracted)"); c->arith = (int)value; }
     else if (k == "deep_halo") { c->deep_halo = (int)value ? 1 : 0; c->deep_pinned = true; }
     else if (k == "skip_exchange") c->skip_exchange = (int)value ? 1 : 0;
+    else if (k == "group_threads") c->group_threads = (int)value ? 1 : 0;
     else if (k == "loopback") c->loopback = (int)value;   // 0 off, 1 device copies, 2 RCCL self send/recv
     else if (k == "pair_ty") { if (value != 8 && value != 12) return fail(LBM_ERR_ARG, "pair_ty must be 8 or 12"); c->pair_ty = (int)value; }
     else if (k == "tune") c->tune = (int)value ? 1 : 0;

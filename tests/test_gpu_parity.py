@@ -351,7 +351,8 @@ def test_group_of_strips_on_one_device_matches_single_domain_bitwise(lbm, plan, 
     must reproduce the one-domain run bit for bit, for every overlap / halo-depth schedule."""
     nx, ny, steps, of = 320, 100, 271, 45
     kw = dict(inlet_velocity=0.06, cylinder_radius=0.12)
-    opts = dict(PLANS[plan], overlap=overlap, deep_halo=deep)
+    # one host thread per strip (default) or the calling thread issuing for all of them
+    opts = dict(PLANS[plan], overlap=overlap, deep_halo=deep, group_threads=0 if (overlap + deep) % 2 else 1)
     with lbm.Context(nx, ny, options=PLANS[plan], **kw) as whole:
         solid = whole.initialise()
         whole.step(steps, of)
