@@ -247,7 +247,14 @@ void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream
                                          else hipLaunchKernelGGL((k_step3_tile<T, TY_, NTH_, NT_, X_, AR_STRICT>), grid, dim3(NTH_), 0, s, a, e); } while (0)
     const bool fast = c->arith == AR_CONTRACTED;
     const int sel = (ty == 12 ? 4 : 0) + (c->use_nt ? 2 : 0) + (c->xcd ? 1 : 0);
-    if (depth == 3) {
+    if (depth == 4) {   // four iterations: 64x8 tiles only (LDS), nt stores and XCD walk as in the plan
+        dim3 grid4((c->nx + 63) / 64, (a.y_cnt + 7) / 8 + (a.y_cnt2 + 7) / 8);
+#define LBM_K4(NT_, X_) do { if (fast) hipLaunchKernelGGL((k_step4_tile<T, 8, 512, NT_, X_, AR_CONTRACTED>), grid4, dim3(512), 0, s, a, e); \
+                             else hipLaunchKernelGGL((k_step4_tile<T, 8, 512, NT_, X_, AR_STRICT>), grid4, dim3(512), 0, s, a, e); } while (0)
+        if (c->use_nt) { if (c->xcd) LBM_K4(true, true); else LBM_K4(true, false); }
+        else { if (c->xcd) LBM_K4(false, true); else LBM_K4(false, false); }
+#undef LBM_K4
+    } else if (depth == 3) {
         switch (sel) {
             case 0: LBM_K3(8, 512, false, false); break;
             case 1: LBM_K3(8, 512, false, true); break;
@@ -283,6 +290,7 @@ int launch_step(lbm_ctx* c, int src, int dst, int t, int mode, hipStream_t s) {
         case MODE_STEP: launch_rows<T, MODE_STEP>(c, a, s); break;
         case 102: launch_fused_rows<T>(c, a, 2, s); break;     // iterations t, t+1
         case 103: launch_fused_rows<T>(c, a, 3, s); break;     // iterations t, t+1, t+2
+        case 104: launch_fused_rows<T>(c, a, 4, s); break;     // iterations t .. t+3 (k_step4_tile, no strip faces)
         case MODE_COLLIDE_ONLY: launch_rows<T, MODE_COLLIDE_ONLY>(c, a, s); break;
         default: break;
     }
@@ -475,8 +483,9 @@ void launch_depth(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s)
 inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool strip_logic, Launch* L) {
     const int t = c->steps_done;
     int depth = 1;
+    const bool any_face = strip_logic && (face_south(c) || face_north(c));
     if (c->fuse > 1) {
-        for (int d = std::min(c->fuse, 3); d >= 2 && depth == 1; --d) {
+        for (int d = std::min(c->fuse, (any_face || c->slide) ? 3 : 4); d >= 2 && depth == 1; --d) {   // (four: k_step4_tile, no faces)
             if (remaining < d + (c->trailing_pair ? 0 : 1)) continue;
             bool ok = true;
             for (int j = 1; j < d; ++j) ok = ok && !(of > 0 && (t + j) % of == 0);
@@ -741,6 +750,7 @@ int choose_plan(lbm_ctx* c) {
             cand.push_back({1, 1, 1, 0, f, 12, 0, "row-interleaved/3-step 64x12/nt-store"});
             cand.push_back({1, 1, 0, 1, f, 12, 1, "row-interleaved/3-step 64x12/alternate/xcd"});
         } else {
+            if (p2) cand.push_back({1, 1, 1, 0, 4, 8, 1, "row-interleaved/4-step 64x8/nt-store/xcd"});
             if (p2) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step sliding 64-column/nt-store", 1});
             if (p2) cand.push_back({1, 1, 0, 0, 3, 12, 1, "row-interleaved/3-step sliding 64-column", 1});
             if (p2) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
@@ -751,6 +761,7 @@ int choose_plan(lbm_ctx* c) {
             cand.push_back({1, 1, 0, 1, 1, 0, 0, "row-interleaved/site/alternate"});
         }
         if (!strips) {
+            if (p2) cand.push_back({0, 0, 1, 0, 4, 8, 1, "planar/4-step 64x8/nt-store/xcd"});
             if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 1, "planar/3-step sliding 64-column/nt-store", 1});
             if (p2) cand.push_back({0, 0, 0, 0, 3, 12, 1, "planar/3-step sliding 64-column", 1});
             if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 1, "planar/3-step 64x12/nt-store/xcd"});
@@ -1652,7 +1663,7 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "alternate") c->alternate = (int)value;
     else if (k == "layout") c->layout = (int)value ? 1 : 0;
     else if (k == "nt") c->use_nt = (int)value ? 1 : 0;
-    else if (k == "fuse") { if (value < 1 || value > 3) return fail(LBM_ERR_ARG, "fuse must be 1, 2 or 3"); c->fuse = (int)value; }
+    else if (k == "fuse") { if (value < 1 || value > 4) return fail(LBM_ERR_ARG, "fuse must be 1, 2, 3 or 4 (4: tile kernel, no strip faces)"); c->fuse = (int)value; }
     else if (k == "pair") c->fuse = (int)value ? 2 : 1;
     else if (k == "trailing_pair") c->trailing_pair = (int)value ? 1 : 0;
     else if (k == "xcd") c->xcd = (int)value ? 1 : 0;
@@ -1702,6 +1713,7 @@ const char* lbm_kernel_name(const lbm_ctx* c) {
     const char* nt = c->use_nt ? "true" : "false";
     const int ar = c->arith;
     if (c->fuse > 1 && c->slide) snprintf(name, sizeof(name), "k_step_slide<%s,%d,6,%s,%d>", t, c->fuse, nt, ar);
+    else if (c->fuse == 4) snprintf(name, sizeof(name), "k_step4_tile<%s,8,512,%s,%s,%d>", t, nt, c->xcd ? "true" : "false", ar);
     else if (c->fuse > 1) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%s,%s,%d>", c->fuse, t, c->pair_ty, c->pair_ty == 12 ? 768 : 512, nt, c->xcd ? "true" : "false", ar);
     else if (use_vec(c)) snprintf(name, sizeof(name), "k_step_vec<%s,%d,0,%s,%d>", t, (int)(16 / c->esize), nt, ar);
     else snprintf(name, sizeof(name), "k_step_site<%s,0,%s,%d>", t, nt, ar);

@@ -22,7 +22,7 @@
 //
 // Kernel families (within one arithmetic mode all evaluate the SAME per-cell operation sequence => bit-identical results):
 //   k_step_site / k_step_vec     one iteration per launch, 144 B of HBM traffic per lattice update (fp64)
-//   k_step2_tile / k_step3_tile  two / three iterations per launch over 64 x TY tiles, intermediate states in LDS:
+//   k_step2/3/4_tile             two / three / four iterations per launch over 64 x TY tiles, intermediate states in LDS:
 //                                84 / 50-60 B per update measured (production path: 93-95 GLUPS strict, 100-104 GLUPS
 //                                contracted at 4096x1024 fp64 on one MI355X)
 //   k_step_slide                 two / three iterations per launch, 64-wide column blocks marching in y over LDS rings
@@ -554,6 +554,131 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
         }
     }
     if (bad) atomicMin(a.unstable_t, a.t + 2);
+}
+
+// Four iterations per launch: k_step3_tile one level deeper (two in-place levels). Region 1 = tile + 3 rings from HBM
+// into LDS (9*(TY+6)*(TX+6)*sizeof(T): 70.5 KB at 64x8 fp64, 35 KB fp32), regions 2 and 3 in place, then the tile.
+// HBM traffic per update ~ (1 + (TX+6)(TY+6)/(TX TY)) * 18 B; redundant collisions 1.45x at 64x8 — worth it where the
+// three-iteration kernel is close to the memory roof (fp32). Needs four valid rows beyond the rows written, so strips
+// (GR = 6 = 2 x 3) never use it; the plan measurement decides elsewhere. Bit-identical to four single launches (tests).
+template <typename T, int TY, int NTH, bool NT, bool XCD, int AR = AR_STRICT>
+__global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs<T> a, const K2Extra<T> e) {
+    constexpr int TX = 64, HW = 3, R1W = TX + 2 * HW, R1H = TY + 2 * HW, LP = R1W;
+    static_assert((R1W - 2) * (R1H - 2) <= 2 * NTH, "two cells per thread at most in the in-place levels");
+    __shared__ T lds[Q][R1H][LP];
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (XCD) {
+        const int nb = gridDim.x * gridDim.y;
+        int b = by * gridDim.x + bx;
+        if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;
+        by = b / gridDim.x; bx = b - by * gridDim.x;
+    }
+    if (a.reverse) by = (int)gridDim.y - 1 - by;
+    const int X0 = bx * TX;
+    int y_end;
+    const int Y0 = band_origin(a, by, TY, y_end);
+    const bool near_cyl = tile_near_cylinder(a, X0, Y0, TX, TY, HW);
+    auto outside_value = [&](bool row_in, bool col_in, int i) -> T { return (row_in && !col_in) ? T(0) : e.feq_in[i]; };
+    // one cell: BCs, stability, collision (solid cells keep w_i); `count` = the cell's instability is reported
+    auto update = [&](T (&f)[Q], int x, int yg, bool count, bool& bad) {
+        bool solid = false;
+        if (near_cyl) solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);   // block-uniform branch
+        T rho_bc, u_out;
+        if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+        if (count) bad |= any_unstable(f);
+        bgk_collide<T, AR>(f, a.tau_inv);
+        if (near_cyl) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
+        }
+    };
+    bool bad = false;
+#pragma unroll
+    for (int r = threadIdx.x; r < R1W * R1H; r += NTH) {                 // level 1 on region 1: iteration t
+        const int ry = r / R1W, rx = r - ry * R1W;
+        const int x = X0 + rx - HW, y = Y0 + ry - HW;
+        const int yg = a.y_start + y;
+        const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+        T f[Q];
+        if (!(row_in && col_in) || y > y_end + HW - 1) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
+        } else {
+            const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
+            update(f, x, yg, true, bad);
+        }
+#pragma unroll
+        for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
+    }
+    if (bad) atomicMin(a.unstable_t, a.t);
+    __syncthreads();
+    // levels 2 and 3 on regions 2 and 3, in place: pull into registers, barrier, compute and overwrite, barrier
+    auto in_place = [&]<int L>() {
+        constexpr int O = L - 1, RW = R1W - 2 * O, RH = R1H - 2 * O;      // region L = region 1 shrunk by L-1 rings
+        T g[2][Q];
+        int cell[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = (int)threadIdx.x + k * NTH;
+            cell[k] = (r < RW * RH) ? r : -1;
+            if (cell[k] >= 0) {
+                const int ry = r / RW + O, rx = r - (r / RW) * RW + O;    // LDS coordinates of the cell
+#pragma unroll
+                for (int i = 0; i < Q; ++i) g[k][i] = lds[i][ry - cy(i)][rx - cx(i)];
+            }
+        }
+        __syncthreads();
+        bool badl = false;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (cell[k] < 0) continue;
+            const int r = cell[k];
+            const int ry = r / RW + O, rx = r - (r / RW) * RW + O;
+            const int x = X0 + rx - HW, y = Y0 + ry - HW;
+            const int yg = a.y_start + y;
+            const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+            T f[Q];
+            if (!(row_in && col_in)) {
+#pragma unroll
+                for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
+            } else {
+#pragma unroll
+                for (int i = 0; i < Q; ++i) f[i] = g[k][i];
+                update(f, x, yg, y <= y_end + HW - L, badl);
+            }
+#pragma unroll
+            for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
+        }
+        if (badl) atomicMin(a.unstable_t, a.t + L - 1);
+        __syncthreads();
+    };
+    in_place.template operator()<2>();
+    in_place.template operator()<3>();
+    bad = false;
+    for (int o = threadIdx.x; o < TX * TY; o += NTH) {                    // level 4 on the tile: iteration t+3
+        const int ly = o / TX, lx = o - ly * TX;
+        const int x = X0 + lx, y = Y0 + ly;
+        if (y >= y_end || x >= a.nx) continue;
+        const int yg = a.y_start + y;
+        T f[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) f[i] = lds[i][ly + HW - cy(i)][lx + HW - cx(i)];
+        const bool solid = near_cyl && is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+        T rho_bc, u_out;
+        if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+        bad |= any_unstable(f);
+        if (solid) continue;
+        bgk_collide<T, AR>(f, a.tau_inv);
+        const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            T* p = a.dst + (long)i * a.plane + c;
+            if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
+        }
+    }
+    if (bad) atomicMin(a.unstable_t, a.t + 3);
 }
 
 // D iterations per launch with a SLIDING WINDOW in y (temporal blocking without y-overlap). A block owns a column of

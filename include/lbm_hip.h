@@ -162,7 +162,8 @@ int  lbm_load_state(lbm_ctx* c, const char* path);
  *   "tune" 1|0    time the candidate plans at lbm_initialise and keep the fastest (default 1); with 0 the plan is
  *                 "layout" 0 planar|1 row-interleaved, "variant" 0 16-B-per-lane kernel|1 one site per thread,
  *                 "nt" non-temporal stores, "alternate" alternate the row walk direction per launch,
- *                 "fuse" 1|2|3 iterations fused per launch through LDS (k_step2_tile / k_step3_tile;
+ *                 "fuse" 1|2|3|4 iterations fused per launch through LDS (k_step2_tile / k_step3_tile / k_step4_tile, the
+ *                 last only for a context without strip faces;
  *                 "pair" 1 == "fuse" 2), "pair_ty" 8|12 tile height, "xcd" XCD-aware tile walk,
  *                 "trailing_pair" 1 lets an lbm_step call end on a fused launch (snapshots then need one more step)
  *                 "slide" 1 the sliding-window fused kernel (k_step_slide) instead of the 2-D tile kernels,

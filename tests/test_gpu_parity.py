@@ -39,6 +39,9 @@ PLANS = {
     # three iterations fused per launch (k_step3_tile)
     "planar-fuse3-8": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=3, pair_ty=8),
     "rowil-fuse3-12-nt-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1),
+    # four iterations fused per launch (k_step4_tile, 64x8 tiles; strips fall back to three)
+    "rowil-fuse4-nt-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1),
+    "planar-fuse4-alt": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=4, pair_ty=8, xcd=0),
     # sliding-window fused kernel (k_step_slide): column blocks marching in y, three / two iterations per launch
     "planar-slide3-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=3, slide=1),
     "rowil-slide3": dict(tune=0, layout=1, variant=1, nt=0, alternate=1, fuse=3, slide=1),
@@ -52,6 +55,7 @@ PLANS = {
     "fast-rowil-slide2": dict(tune=0, layout=1, variant=1, nt=0, alternate=0, fuse=2, slide=1, arith=1),
     "fast-rowil-fuse3-12-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
     "fast-planar-pair8": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, pair=1, pair_ty=8, arith=1),
+    "fast-rowil-fuse4-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
 }
 FAST = [k for k, v in PLANS.items() if v and v.get("arith")]
 
@@ -167,7 +171,7 @@ def test_golden_unstable_timestep(lbm, name, plan):
 ])
 @pytest.mark.parametrize("plan", ["auto", "planar-site", "rowil-vec-nt-alt", "planar-pair8-nt", "rowil-pair12-alt",
                                   "planar-fuse3-8", "rowil-fuse3-12-nt-xcd", "planar-slide3-nt", "rowil-slide3",
-                                  "rowil-slide2-nt"] + FAST)
+                                  "rowil-slide2-nt", "rowil-fuse4-nt-xcd", "planar-fuse4-alt"] + FAST)
 def test_against_oracle(lbm, nx, ny, steps, kw, plan):
     from oracle.oracle import Oracle, make_params
     of = max(1, steps // 5)
@@ -205,7 +209,8 @@ def test_contracted_arithmetic_is_plan_independent(lbm):
     nx, ny, steps, of = 320, 90, 240, 60
     kw = dict(inlet_velocity=0.07, cylinder_radius=0.1)
     out = []
-    for plan in ("fast-site", "fast-vec-alt", "fast-slide3-nt", "fast-rowil-slide2", "fast-rowil-fuse3-12-xcd", "fast-planar-pair8"):
+    for plan in ("fast-site", "fast-vec-alt", "fast-slide3-nt", "fast-rowil-slide2", "fast-rowil-fuse3-12-xcd", "fast-planar-pair8",
+                 "fast-rowil-fuse4-xcd"):
         with lbm.Context(nx, ny, options=PLANS[plan], **kw) as ctx:
             ctx.initialise()
             ctx.step(steps, of)
@@ -612,7 +617,7 @@ def test_fp32_tracks_fp64_on_fused_plans_1024x256(lbm):
         ctx.step(steps, 0)
         ref = ctx.macros()
     out = {}
-    for plan in ("auto", "rowil-fuse3-12-nt-xcd", "planar-slide3-nt", "rowil-slide2-nt", "planar-site"):
+    for plan in ("auto", "rowil-fuse3-12-nt-xcd", "rowil-fuse4-nt-xcd", "planar-slide3-nt", "rowil-slide2-nt", "planar-site"):
         with lbm.Context(nx, ny, precision="f32", options=PLANS[plan], **kw) as ctx:
             ctx.initialise()
             ctx.step(steps, 0)
@@ -653,7 +658,7 @@ def test_c5_grid_16384x4096_fp32_single_gpu(lbm):
     assert np.isfinite(rho).all() and 0.9 < rho.min() and rho.max() < 1.1
     assert abs(float(ux[ny // 4, nx // 2]) - 0.01627604) < 2e-3 and float(np.abs(uy).max()) < 0.1
     assert [r[0] for r in log] == [0, 150]
-    for options in (None, PLANS["rowil-fuse3-12-nt-xcd"], PLANS["planar-slide3-nt"], PLANS["rowil-site-nt"]):
+    for options in (None, PLANS["rowil-fuse3-12-nt-xcd"], PLANS["rowil-fuse4-nt-xcd"], PLANS["planar-slide3-nt"], PLANS["rowil-site-nt"]):
         m2, log2, _, _ = run(options)
         for a, b in zip((rho, ux, uy), m2):
             assert np.array_equal(a, b), options

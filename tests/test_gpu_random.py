@@ -43,7 +43,7 @@ def cases(n=36, seed=20260104):
         cx += float(rng.uniform(-0.02, 0.02)) if cyl not in (1,) else 0.0
         steps = int(rng.integers(1, 90))
         of = int(rng.integers(1, 25))
-        fuse = int(rng.integers(1, 4))
+        fuse = int(rng.integers(1, 5))
         opts = dict(tune=0, layout=int(rng.integers(0, 2)), variant=int(rng.integers(0, 2)), nt=int(rng.integers(0, 2)),
                     alternate=int(rng.integers(0, 2)), fuse=fuse, pair_ty=int(rng.choice([8, 12])),
                     xcd=int(rng.integers(0, 2)), slide=int(rng.integers(0, 2)) if fuse > 1 else 0, arith=int(rng.integers(0, 2)))

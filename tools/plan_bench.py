@@ -36,6 +36,9 @@ PLANS = {
     "ft3-nt1-alt1": dict(tune=0, layout=1, variant=1, nt=1, alternate=1, fuse=3, pair_ty=12, xcd=1, arith=1),
     "ft3-planar-xcd": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
     "ft3-planar-xcd-alt": dict(tune=0, layout=0, variant=0, nt=1, alternate=1, fuse=3, pair_ty=12, xcd=1, arith=1),
+    "tile4": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1),
+    "fast-tile4": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
+    "fast-tile4-planar": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
     "fast-auto": dict(arith=1),
     "fast-site": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1, arith=1),
     "fast-vec": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=1, arith=1),
