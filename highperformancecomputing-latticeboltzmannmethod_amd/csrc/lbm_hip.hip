@@ -773,28 +773,45 @@ int choose_plan(lbm_ctx* c) {
         }
     }
     free_buffers(c);                                // a second lbm_initialise starts from no population buffers
-    void* best_buf[2] = {nullptr, nullptr};
-    float best_ms = 1e30f;
-    int best = -1;
-    auto drop_best = [&]() { for (void*& q : best_buf) if (q) { (void)hipFree(q); q = nullptr; } };
+    // First round: every candidate once; the three fastest keep their allocations. Final round: those three again with
+    // longer windows (candidates within 2 % of each other are common and the first round cannot tell them apart).
+    struct Kept { int k; float ms; void* buf[2]; };
+    std::vector<Kept> top;
+    auto drop_all = [&]() { for (Kept& t : top) for (void*& q : t.buf) if (q) { (void)hipFree(q); q = nullptr; } top.clear(); };
+    const bool room = can_tune && 4 * need + (1u << 28) < free_b;     // three kept allocations + the one being probed
+    const size_t keep = room ? 3 : 1;
     for (size_t k = 0; k < cand.size(); ++k) {
         apply_plan(c, cand[k]);
-        c->buf[0] = c->buf[1] = nullptr;            // keep the best allocation alive while the next one is probed
+        c->buf[0] = c->buf[1] = nullptr;            // keep the best allocations alive while the next one is probed
         int rc = alloc_buffers(c);
-        if (rc) { free_buffers(c); drop_best(); return rc; }
+        if (rc) { free_buffers(c); drop_all(); return rc; }
         float ms = 0.f;
         if (cand.size() > 1) {
             rc = time_plan<T>(c, &ms);
-            if (rc) { free_buffers(c); drop_best(); return rc; }
+            if (rc) { free_buffers(c); drop_all(); return rc; }
         }
-        if (ms < best_ms) {
-            for (void* q : best_buf) if (q) (void)hipFree(q);
-            best_buf[0] = c->buf[0]; best_buf[1] = c->buf[1];
-            best_ms = ms; best = (int)k;
-        } else {
-            free_buffers(c);
-        }
+        top.push_back({(int)k, ms, {c->buf[0], c->buf[1]}});
+        c->buf[0] = c->buf[1] = nullptr;
+        std::stable_sort(top.begin(), top.end(), [](const Kept& x, const Kept& y) { return x.ms < y.ms; });
+        while (top.size() > keep) { for (void* q : top.back().buf) if (q) (void)hipFree(q); top.pop_back(); }
     }
+    if (top.size() > 1) {
+        for (Kept& t : top) {
+            apply_plan(c, cand[(size_t)t.k]);
+            c->buf[0] = t.buf[0]; c->buf[1] = t.buf[1];
+            float a = 0.f, b = 0.f;
+            int rc = time_plan<T>(c, &a);
+            if (!rc) rc = time_plan<T>(c, &b);
+            c->buf[0] = c->buf[1] = nullptr;
+            if (rc) { drop_all(); return rc; }
+            t.ms = std::min(a, b);
+        }
+        std::stable_sort(top.begin(), top.end(), [](const Kept& x, const Kept& y) { return x.ms < y.ms; });
+        while (top.size() > 1) { for (void* q : top.back().buf) if (q) (void)hipFree(q); top.pop_back(); }
+    }
+    const int best = top[0].k;
+    const float best_ms = top[0].ms;
+    void* best_buf[2] = {top[0].buf[0], top[0].buf[1]};
     apply_plan(c, cand[best]);
     c->buf[0] = best_buf[0]; c->buf[1] = best_buf[1];
     c->launches_total = 0;
