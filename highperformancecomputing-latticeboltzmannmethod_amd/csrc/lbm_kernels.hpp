@@ -454,106 +454,139 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
     const int Y0 = band_origin(a, by, TY, y_end);
     const bool near_cyl = tile_near_cylinder(a, X0, Y0, TX, TY, 2);
     auto outside_value = [&](bool row_in, bool col_in, int i) -> T { return (row_in && !col_in) ? T(0) : e.feq_in[i]; };
-    bool bad = false;
+    // LEAN (block-uniform): the tile and its two rings lie strictly inside the domain, the tile is full, nothing is near
+    // the cylinder — every cell of all three regions is a plain fluid cell: no boundary, ghost, solid or validity logic.
+    const int yg0 = a.y_start + Y0;
+    const bool lean = !near_cyl && X0 >= 3 && X0 + TX + 2 <= a.nx - 1 && yg0 >= 3 && yg0 + TY + 2 <= a.ny_glob - 1 &&
+                      Y0 + TY <= y_end;
+    auto run = [&]<bool LEAN>() {
+        bool bad = false;
 #pragma unroll
-    for (int r = threadIdx.x; r < R1W * R1H; r += NTH) {                 // phase 1: iteration t
-        const int ry = r / R1W, rx = r - ry * R1W;
-        const int x = X0 + rx - 2, y = Y0 + ry - 2;
-        const int yg = a.y_start + y;
-        const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
-        T f[Q];
-        if (!(row_in && col_in) || y > y_end + 1) {
+        for (int r = threadIdx.x; r < R1W * R1H; r += NTH) {                 // phase 1: iteration t
+            const int ry = r / R1W, rx = r - ry * R1W;
+            const int x = X0 + rx - 2, y = Y0 + ry - 2;
+            const int yg = a.y_start + y;
+            T f[Q];
+            bool inside = true;
+            if (!LEAN) {
+                const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+                inside = row_in && col_in && y <= y_end + 1;
+                if (!inside) {
 #pragma unroll
-            for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
-        } else {
+                    for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
+                }
+            }
+            if (inside) {
+                const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+#pragma unroll
+                for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
+                if (LEAN) {
+                    bad |= any_unstable(f);
+                    bgk_collide<T, AR>(f, a.tau_inv);
+                } else {
+                    bool solid = false;
+                    if (near_cyl) solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);   // block-uniform branch
+                    T rho_bc, u_out;
+                    if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+                    bad |= any_unstable(f);
+                    bgk_collide<T, AR>(f, a.tau_inv);
+                    if (near_cyl) {            // solid cells keep w_i (the collision result of such a cell is discarded)
+#pragma unroll
+                        for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
+        }
+        if (bad) atomicMin(a.unstable_t, a.t);
+        __syncthreads();
+        // phase 2: iteration t+1 on region 2, in place
+        T g[2][Q];
+        int cell[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = threadIdx.x + k * NTH;
+            cell[k] = (r < R2W * R2H) ? r : -1;
+            if (cell[k] >= 0) {
+                const int ry = r / R2W + 1, rx = r - (r / R2W) * R2W + 1;    // LDS coordinates of the cell
+#pragma unroll
+                for (int i = 0; i < Q; ++i) g[k][i] = lds[i][ry - cy(i)][rx - cx(i)];
+            }
+        }
+        __syncthreads();
+        bad = false;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (cell[k] < 0) continue;
+            const int r = cell[k];
+            const int ry = r / R2W + 1, rx = r - (r / R2W) * R2W + 1;
+            const int x = X0 + rx - 2, y = Y0 + ry - 2;
+            const int yg = a.y_start + y;
+            T f[Q];
+            bool inside = true;
+            if (!LEAN) {
+                const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+                inside = row_in && col_in;
+                if (!inside) {
+#pragma unroll
+                    for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
+                }
+            }
+            if (inside) {
+#pragma unroll
+                for (int i = 0; i < Q; ++i) f[i] = g[k][i];
+                if (LEAN) {
+                    bad |= any_unstable(f);
+                    bgk_collide<T, AR>(f, a.tau_inv);
+                } else {
+                    bool solid = false;
+                    if (near_cyl) solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);   // block-uniform branch
+                    T rho_bc, u_out;
+                    if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+                    if (y <= y_end) bad |= any_unstable(f);
+                    bgk_collide<T, AR>(f, a.tau_inv);
+                    if (near_cyl) {            // solid cells keep w_i (the collision result of such a cell is discarded)
+#pragma unroll
+                        for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
+        }
+        if (bad) atomicMin(a.unstable_t, a.t + 1);
+        __syncthreads();
+        bad = false;
+        for (int o = threadIdx.x; o < TX * TY; o += NTH) {                    // phase 3: iteration t+2 on the tile
+            const int ly = o / TX, lx = o - ly * TX;
+            const int x = X0 + lx, y = Y0 + ly;
+            if (!LEAN && (y >= y_end || x >= a.nx)) continue;
+            const int yg = a.y_start + y;
+            T f[Q];
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = lds[i][ly + 2 - cy(i)][lx + 2 - cx(i)];
+            if (LEAN) {
+                bad |= any_unstable(f);
+            } else {
+                const bool solid = near_cyl && is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+                T rho_bc, u_out;
+                if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+                bad |= any_unstable(f);
+                if (solid) continue;
+            }
+            bgk_collide<T, AR>(f, a.tau_inv);
             const long c = (long)(y + GR) * a.pitch + a.xoff + x;
 #pragma unroll
-            for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
-            bool solid = false;
-            if (near_cyl) solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);   // block-uniform branch
-            T rho_bc, u_out;
-            if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
-            bad |= any_unstable(f);
-            bgk_collide<T, AR>(f, a.tau_inv);
-            if (near_cyl) {                    // solid cells keep w_i (the collision result of such a cell is discarded)
-#pragma unroll
-                for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
+            for (int i = 0; i < Q; ++i) {
+                T* p = a.dst + (long)i * a.plane + c;
+                if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
             }
         }
-#pragma unroll
-        for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
-    }
-    if (bad) atomicMin(a.unstable_t, a.t);
-    __syncthreads();
-    // phase 2: iteration t+1 on region 2, in place
-    T g[2][Q];
-    int cell[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int r = threadIdx.x + k * NTH;
-        cell[k] = (r < R2W * R2H) ? r : -1;
-        if (cell[k] >= 0) {
-            const int ry = r / R2W + 1, rx = r - (r / R2W) * R2W + 1;    // LDS coordinates of the cell
-#pragma unroll
-            for (int i = 0; i < Q; ++i) g[k][i] = lds[i][ry - cy(i)][rx - cx(i)];
-        }
-    }
-    __syncthreads();
-    bad = false;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (cell[k] < 0) continue;
-        const int r = cell[k];
-        const int ry = r / R2W + 1, rx = r - (r / R2W) * R2W + 1;
-        const int x = X0 + rx - 2, y = Y0 + ry - 2;
-        const int yg = a.y_start + y;
-        const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
-        T f[Q];
-        if (!(row_in && col_in)) {
-#pragma unroll
-            for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
-        } else {
-#pragma unroll
-            for (int i = 0; i < Q; ++i) f[i] = g[k][i];
-            bool solid = false;
-            if (near_cyl) solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);   // block-uniform branch
-            T rho_bc, u_out;
-            if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
-            if (y <= y_end) bad |= any_unstable(f);
-            bgk_collide<T, AR>(f, a.tau_inv);
-            if (near_cyl) {                    // solid cells keep w_i (the collision result of such a cell is discarded)
-#pragma unroll
-                for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
-    }
-    if (bad) atomicMin(a.unstable_t, a.t + 1);
-    __syncthreads();
-    bad = false;
-    for (int o = threadIdx.x; o < TX * TY; o += NTH) {                    // phase 3: iteration t+2 on the tile
-        const int ly = o / TX, lx = o - ly * TX;
-        const int x = X0 + lx, y = Y0 + ly;
-        if (y >= y_end || x >= a.nx) continue;
-        const int yg = a.y_start + y;
-        T f[Q];
-#pragma unroll
-        for (int i = 0; i < Q; ++i) f[i] = lds[i][ly + 2 - cy(i)][lx + 2 - cx(i)];
-        const bool solid = near_cyl && is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
-        T rho_bc, u_out;
-        if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
-        bad |= any_unstable(f);
-        if (solid) continue;
-        bgk_collide<T, AR>(f, a.tau_inv);
-        const long c = (long)(y + GR) * a.pitch + a.xoff + x;
-#pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            T* p = a.dst + (long)i * a.plane + c;
-            if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
-        }
-    }
-    if (bad) atomicMin(a.unstable_t, a.t + 2);
+        if (bad) atomicMin(a.unstable_t, a.t + 2);
+    };
+    if (lean) run.template operator()<true>();
+    else run.template operator()<false>();
 }
 
 // Four iterations per launch: k_step3_tile one level deeper (two in-place levels). Region 1 = tile + 3 rings from HBM
