@@ -612,8 +612,17 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs
     const int Y0 = band_origin(a, by, TY, y_end);
     const bool near_cyl = tile_near_cylinder(a, X0, Y0, TX, TY, HW);
     auto outside_value = [&](bool row_in, bool col_in, int i) -> T { return (row_in && !col_in) ? T(0) : e.feq_in[i]; };
+    // LEAN (block-uniform): tile + three rings strictly inside the domain, full tile, nothing near the cylinder
+    const int yg0 = a.y_start + Y0;
+    const bool lean = !near_cyl && X0 >= HW + 1 && X0 + TX + HW <= a.nx - 1 && yg0 >= HW + 1 && yg0 + TY + HW <= a.ny_glob - 1 &&
+                      Y0 + TY <= y_end;
     // one cell: BCs, stability, collision (solid cells keep w_i); `count` = the cell's instability is reported
     auto update = [&](T (&f)[Q], int x, int yg, bool count, bool& bad) {
+        if (lean) {                                 // block-uniform
+            bad |= any_unstable(f);
+            bgk_collide<T, AR>(f, a.tau_inv);
+            return;
+        }
         bool solid = false;
         if (near_cyl) solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);   // block-uniform branch
         T rho_bc, u_out;
