@@ -212,6 +212,7 @@ template <typename T>
 void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s) {
     K2Extra<T> e;
     e.feq_in = static_cast<const T*>(c->d_feq);
+    e.small = (c->total * c->esize + 512 < (size_t(1) << 32)) ? 1 : 0;
     if (c->slide) {
         // Column blocks of 64 cells marching up segments of seg_h rows in bands of SB rows. Segments are sized so that
         // every block of the launch is resident at once (two blocks per CU): one wave of blocks, no tail.

@@ -350,7 +350,10 @@ __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
 // feq_in: the nine initial-equilibrium values (permanent content of physical N/S ghost rows and corner ghosts), in
 // device memory: they are needed by the few cells of a region that lie outside the domain only, and passing them by
 // value would pin 18 scalar registers for the whole kernel (the fused kernels are SGPR-bound).
-template <typename T> struct K2Extra { const T* feq_in; };
+template <typename T> struct K2Extra {
+    const T* feq_in;
+    int small;   // the buffer is below 4 GiB: the lean path of k_step3_tile may address it with 32-bit byte offsets
+};
 
 template <typename T, int TY, int NTH, bool NT, bool XCD = false, int AR = AR_STRICT>
 __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Extra<T> e) {
@@ -458,7 +461,11 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
     // the cylinder — every cell of all three regions is a plain fluid cell: no boundary, ghost, solid or validity logic.
     const int yg0 = a.y_start + Y0;
     const bool lean = !near_cyl && X0 >= 3 && X0 + TX + 2 <= a.nx - 1 && yg0 >= 3 && yg0 + TY + 2 <= a.ny_glob - 1 &&
-                      Y0 + TY <= y_end;
+                      Y0 + TY <= y_end && e.small;
+    // (lean path) one uniform base per buffer + a 32-bit byte offset per access: a vector add per plane instead of a 64-bit one
+    const char* const sbase = reinterpret_cast<const char*>(a.src);
+    char* const dbase = reinterpret_cast<char*>(a.dst);
+    const unsigned pitchB = (unsigned)a.pitch * (unsigned)sizeof(T), planeB = (unsigned)a.plane * (unsigned)sizeof(T);
     auto run = [&]<bool LEAN>() {
         bool bad = false;
 #pragma unroll
@@ -477,9 +484,16 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
                 }
             }
             if (inside) {
-                const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+                if (LEAN) {
+                    const unsigned c = (unsigned)(y + GR) * pitchB + (unsigned)(a.xoff + x) * (unsigned)sizeof(T);
 #pragma unroll
-                for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
+                    for (int i = 0; i < Q; ++i)
+                        f[i] = *reinterpret_cast<const T*>(sbase + (c + (unsigned)i * planeB - (unsigned)cy(i) * pitchB - (unsigned)(cx(i) * (int)sizeof(T))));
+                } else {
+                    const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+#pragma unroll
+                    for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
+                }
                 if (LEAN) {
                     bad |= any_unstable(f);
                     bgk_collide<T, AR>(f, a.tau_inv);
@@ -576,11 +590,20 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
                 if (solid) continue;
             }
             bgk_collide<T, AR>(f, a.tau_inv);
-            const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+            if (LEAN) {
+                const unsigned c = (unsigned)(y + GR) * pitchB + (unsigned)(a.xoff + x) * (unsigned)sizeof(T);
 #pragma unroll
-            for (int i = 0; i < Q; ++i) {
-                T* p = a.dst + (long)i * a.plane + c;
-                if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
+                for (int i = 0; i < Q; ++i) {
+                    T* p = reinterpret_cast<T*>(dbase + (c + (unsigned)i * planeB));
+                    if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
+                }
+            } else {
+                const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+#pragma unroll
+                for (int i = 0; i < Q; ++i) {
+                    T* p = a.dst + (long)i * a.plane + c;
+                    if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
+                }
             }
         }
         if (bad) atomicMin(a.unstable_t, a.t + 2);

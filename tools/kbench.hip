@@ -223,7 +223,7 @@ void suite(int nx, int ny, long pad, int reps, int rounds, bool rowil, int pitch
             hv[0] = (T)(wgt<double>(0) * (1.0 - 1.5 * usq));
             for (int i = 1; i < Q; ++i) { const double cu = cx(i) * ux; hv[i] = (T)(wgt<double>(i) * (((1.0 + 3.0 * cu) - t3) + 4.5 * cu * cu)); }
             T* dv; CK(hipMalloc(&dv, sizeof(hv))); CK(hipMemcpy(dv, hv, sizeof(hv), hipMemcpyHostToDevice));
-            ex.feq_in = dv;
+            ex.feq_in = dv; ex.small = 1;
         }
         auto g2 = [&](int ty) { return dim3(nx / 64, (ny + ty - 1) / ty); };
         vars.push_back({"step2 TY8 512t", [=](const KArgs<T>& a) { hipLaunchKernelGGL((k_step2_tile<T, 8, 512, false>), g2(8), dim3(512), 0, s, a, ex); }, {}});
