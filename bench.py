@@ -247,8 +247,15 @@ def main():
         kernel = ctx.kernel_name()
         traffic, tnote = measured_traffic(nx, local_ny, args.precision, kernel)
         equiv = launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        m = re.match(r"k_step(\d)_tile|k_step_slide<\w+,(\d)", kernel)
+        plan_depth = int(m.group(1) or m.group(2)) if m else 1
+        if traffic and abs(ipl - plan_depth) > 0.01 * plan_depth:
+            # a short call mixes launch depths (e.g. 20 = 4+4+3+3+3+3, or a two-iteration tail): the PMC figure belongs to the
+            # plan's kernel at its own depth; scale it to the mean depth of the timed launches
+            traffic = int(traffic * ipl / plan_depth)
+            tnote += f"; scaled by {ipl:.3f}/{plan_depth} (mixed launch depths in a {args.steps}-step call)"
         if traffic:
-            achieved, basis = traffic / (kernel_ms * 1e-3) / 1e9, "measured HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE) / live launch time"
+            achieved, basis = traffic / (kernel_ms * 1e-3) / 1e9, "measured HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE; " + tnote + ") / live launch time"
         else:   # the least a fused launch can move: read P_t once, write P_{t+d} once
             achieved, basis = (launch_bytes / ipl) / (kernel_ms * 1e-3) / 1e9, "fused minimum (one read + one write of the lattice per launch) / live launch time; " + tnote
         hr = lbm.Context.HALO_ROWS

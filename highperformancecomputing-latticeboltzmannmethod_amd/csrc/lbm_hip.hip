@@ -486,8 +486,15 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
     int depth = 1;
     const bool any_face = strip_logic && (face_south(c) || face_north(c));
     if (c->fuse > 1) {
-        for (int d = std::min(c->fuse, (any_face || c->slide) ? 3 : 4); d >= 2 && depth == 1; --d) {   // (four: k_step4_tile, no faces)
-            if (remaining < d + (c->trailing_pair ? 0 : 1)) continue;
+        const int room = remaining - (c->trailing_pair ? 0 : 1);       // iterations a fused launch may take now
+        int dmax = std::min(c->fuse, (any_face || c->slide) ? 3 : 4);  // (four: k_step4_tile, no faces)
+        // A three-iteration plan leaves a one- or two-iteration launch at the end of a call whose length is not a
+        // multiple of three, which runs at half the rate. Where the four-iteration kernel is usable, one (remainder 1)
+        // or two (remainder 2) four-iteration launches absorb it: 20 = 4 + 4 + 3 + 3 + 3 + 3.
+        if (c->fuse == 3 && dmax == 3 && !any_face && !c->slide && of <= 0 && (room % 3 == 1 ? room >= 4 : (room % 3 == 2 && room >= 8)))
+            dmax = 4;
+        for (int d = dmax; d >= 2 && depth == 1; --d) {
+            if (room < d) continue;
             bool ok = true;
             for (int j = 1; j < d; ++j) ok = ok && !(of > 0 && (t + j) % of == 0);
             if (ok) depth = d;
