@@ -6,7 +6,7 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one loop body of Solver::run (exchange + stream + BCs + stability + collision) over the whole lattice; the
-library fuses up to three consecutive steps into one kernel launch (intermediate states in LDS). Workload at every N:
+library fuses up to three (four on a single strip) consecutive steps into one kernel launch (intermediate states in LDS). Workload at every N:
 BASELINE.json configs[2], the 4096x1024 fp64 cylinder at Re=200 (tau=0.6, u_in=0.06510417) — the grid the metric is
 quoted on ("4096x1024 D2Q9 at 1/2/4/8 GPUs"), so N>1 is STRONG scaling: the rows are cut into N strips, one process per
 GPU, LBM_HALO_ROWS edge rows x 9 populations per face exchanged with RCCL send/recv once per two launches (schedule

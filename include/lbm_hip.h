@@ -67,7 +67,8 @@ void lbm_destroy(lbm_ctx* c);
 int  lbm_initialise(lbm_ctx* c, int* solid_count_out);
 
 /* `nsteps` loop bodies of Solver::run (LBMSolver.h:49-60): exchange + stream + BCs + stability of iteration
- * t, fused with collision_step() of iteration t+1; up to three consecutive iterations share one kernel launch
+ * t, fused with collision_step() of iteration t+1; up to three (four for a context without strip faces) consecutive
+ * iterations share one kernel launch
  * (intermediate states stay in LDS; results are bit-identical to one launch per iteration). Asynchronous on the
  * context's streams. If output_frequency > 0, record_forces is evaluated on-device for every
  * t % output_frequency == 0 inside the range (LBMSolver.h:52-54) and appended to the force log. The last iteration
