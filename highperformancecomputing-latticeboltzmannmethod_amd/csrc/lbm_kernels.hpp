@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
 
 // Three iterations per launch. Same idea one level deeper; the LDS image is reused in place:
 //   phase 1  region 1 = tile + 2 rings: P_{t+1} from global P_t into LDS (9*(TY+4)*(TX+4)*sizeof(T): 78 KB at 64x12
-//            fp64, two blocks per CU);
+//            fp64, two blocks of 1024 threads per CU = all 32 wave slots; the lean path needs 48 VGPRs);
 //   phase 2  region 2 = tile + 1 ring: every thread first pulls its (<= 2) cells' nine values of P_{t+1} from LDS into
 //            registers, barrier, then computes P_{t+2} and writes it IN PLACE (no second LDS image);
 //   phase 3  the tile: pull P_{t+2} from LDS, BCs, collide, store P_{t+3}.
