@@ -104,7 +104,7 @@ def cpu_baseline(nx, ny, u_in, budget_s=12.0):
                       f"{steps} steps, {threads} OpenMP threads"}
 
 
-def measured_traffic(nx, local_ny, precision, kernel):
+def measured_traffic(nx, local_ny, precision, kernel, layout=""):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json; FETCH_SIZE and
     WRITE_SIZE cannot be collected inside a timed run). Returns (bytes | None, note)."""
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
@@ -113,9 +113,10 @@ def measured_traffic(nx, local_ny, precision, kernel):
     except Exception as e:
         return None, f"profiles/traffic.json unreadable ({e})"
     key = f"{nx}x{local_ny}_{precision}"
-    for ent in tj.get(key, []) if isinstance(tj.get(key), list) else [tj.get(key)] if tj.get(key) else []:
-        if ent.get("kernel", "").replace(" ", "") == kernel.replace(" ", ""):
-            return ent.get("hbm_bytes_per_launch"), ent.get("source", "profiles/traffic.json")
+    ents = [e for e in (tj.get(key) or []) if e.get("kernel", "").replace(" ", "") == kernel.replace(" ", "")]
+    ents.sort(key=lambda e: e.get("layout", "") != layout)      # the pass taken in the same layout first
+    if ents:
+        return ents[0].get("hbm_bytes_per_launch"), ents[0].get("source", "profiles/traffic.json")
     return None, f"no FETCH_SIZE/WRITE_SIZE pass committed for {key} with {kernel} (profiles/traffic.json)"
 
 
@@ -245,7 +246,7 @@ def main():
         # through LDS); algorithmic bytes per launch = lattice updates per launch x 144 B (fp64) / 72 B (fp32)
         launch_bytes = int(nx * local_ny * bpl * ipl)
         kernel = ctx.kernel_name()
-        traffic, tnote = measured_traffic(nx, local_ny, args.precision, kernel)
+        traffic, tnote = measured_traffic(nx, local_ny, args.precision, kernel, ctx.plan().split("/")[0])
         equiv = launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         m = re.match(r"k_step(\d)_tile|k_step_slide<\w+,(\d)", kernel)
         plan_depth = int(m.group(1) or m.group(2)) if m else 1

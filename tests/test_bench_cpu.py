@@ -30,7 +30,7 @@ def test_traffic_table_is_wellformed_and_covers_the_baseline_grids():
 
 def test_measured_traffic_lookup_and_labels():
     b = load_bench()
-    t, note = b.measured_traffic(4096, 1024, "f64", "k_step3_tile<double,12,768,true,true,1>")
+    t, note = b.measured_traffic(4096, 1024, "f64", "k_step3_tile<double,12,1024,true,true,1>", "row-interleaved")
     assert t and 600e6 < t < 700e6 and "profiles/r02" in note
     t, note = b.measured_traffic(4096, 1024, "f64", "k_step_site<double,0,true,1>")
     assert t is None and "no FETCH_SIZE/WRITE_SIZE pass" in note

@@ -41,7 +41,8 @@ def main():
             "write_bytes": int(write), "launches_sampled": vals["FETCH_SIZE"][1],
             "iterations_per_launch": round(line["roofline"]["iterations_per_launch"]),
             "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"],
-            "arithmetic": line["config"].get("arithmetic", "")[:20], "source": os.path.relpath(summ, ROOT),
+            "arithmetic": line["config"].get("arithmetic", "")[:20], "layout": (lambda pl: "row-interleaved" if pl.startswith("fixed by options") else pl.split("/")[0])(line["config"].get("plan", "")),   # (the forced alt_* runs use --set layout=1)
+            "source": os.path.relpath(summ, ROOT),
             "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over `python3 bench.py ...` "
                       "(tools/pmc_traffic.sh); KiB -> B; FETCH_SIZE x2 (gfx950 correction)"})
     json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
