@@ -85,6 +85,8 @@ struct lbm_ctx {
     int fuse = 1;        // iterations fused per launch where the schedule allows: 1, 2 (k_step2_tile) or 3 (k_step3_tile)
     int pair_ty = 8;     // tile height of the fused kernels (8 or 12)
     int xcd = 0;         // fused kernels: remap blocks so that each XCD walks a contiguous run of tiles
+    bool deep_now = false;   // the launch being issued is the plan's deep launch (set by plan_launch)
+    int deep = 0;        // 1..3: k_stepd_tile shape (6/7/8 iterations per launch on an LDS-filling tile); whole-domain launches only
     int slide = 0;       // fused launches use the sliding-window kernel k_step_slide (column blocks marching in y)
     int arith = 0;       // collision arithmetic: 0 strict IEEE op-by-op (bit-identical to the oracle), 1 contracted (FMA +
                          // one reciprocal, as the reference's -ffast-math -mfma build permits); see lbm_kernels.hpp Arith
@@ -207,12 +209,22 @@ void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
     }
 }
 
+// "deep" plans (k_stepd_tile): shape id -> iterations per launch and tile
+inline int deep_depth(int id) {
+    static const int d[6] = {0, 6, 7, 8, 5, 6};
+    return id >= 0 && id <= 5 ? d[id] : 0;
+}
+inline const char* deep_tile(int id) {
+    static const char* t[6] = {"", "64,16", "64,16", "32,32", "32,16", "32,16"};
+    return id >= 0 && id <= 5 ? t[id] : "";
+}
+
 // A fused kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt): iterations a.t .. a.t + depth - 1 (depth 2 or 3).
 template <typename T>
 void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s) {
     K2Extra<T> e;
     e.feq_in = static_cast<const T*>(c->d_feq);
-    e.small = (c->total * c->esize + 512 < (size_t(1) << 32)) ? 1 : 0;
+    e.small = ((c->total + (size_t)c->pitch) * c->esize + 1024 < (size_t(1) << 32)) ? 1 : 0;   // 32-bit byte offsets (+ one row of slack)
     if (c->slide) {
         // Column blocks of 64 cells marching up segments of seg_h rows in bands of SB rows. Segments are sized so that
         // every block of the launch is resident at once (two blocks per CU): one wave of blocks, no tail.
@@ -238,6 +250,24 @@ void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream
             default: LBM_KS(3, true, AR_CONTRACTED); break;
         }
 #undef LBM_KS
+        return;
+    }
+    if (c->deep_now && depth == deep_depth(c->deep)) {    // D iterations on a deep tile (k_stepd_tile; whole-domain launches)
+        const bool fastd = c->arith == AR_CONTRACTED;
+#define LBM_KD(TX_, TY_, D_) do { \
+        dim3 gridd((c->nx + TX_ - 1) / TX_, (a.y_cnt + TY_ - 1) / TY_ + (a.y_cnt2 + TY_ - 1) / TY_); \
+        if (c->use_nt) { if (fastd) hipLaunchKernelGGL((k_stepd_tile<T, TX_, TY_, D_, true, true, AR_CONTRACTED>), gridd, dim3(TX_ * TY_), 0, s, a, e); \
+                         else hipLaunchKernelGGL((k_stepd_tile<T, TX_, TY_, D_, true, true, AR_STRICT>), gridd, dim3(TX_ * TY_), 0, s, a, e); } \
+        else { if (fastd) hipLaunchKernelGGL((k_stepd_tile<T, TX_, TY_, D_, false, true, AR_CONTRACTED>), gridd, dim3(TX_ * TY_), 0, s, a, e); \
+               else hipLaunchKernelGGL((k_stepd_tile<T, TX_, TY_, D_, false, true, AR_STRICT>), gridd, dim3(TX_ * TY_), 0, s, a, e); } } while (0)
+        switch (c->deep) {
+            case 1: LBM_KD(64, 16, 6); break;
+            case 2: LBM_KD(64, 16, 7); break;
+            case 3: LBM_KD(32, 32, 8); break;
+            case 4: LBM_KD(32, 16, 5); break;       // 512-thread blocks: two per CU in fp64
+            default: LBM_KD(32, 16, 6); break;
+        }
+#undef LBM_KD
         return;
     }
     const int ty = c->pair_ty;
@@ -285,7 +315,6 @@ void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream
 #undef LBM_K3
 }
 inline bool pair_possible(const lbm_ctx*) { return true; }   // partial tiles cover any nx
-
 template <typename T>
 int launch_step(lbm_ctx* c, int src, int dst, int t, int mode, hipStream_t s) {
     KArgs<T> a = make_kargs<T>(c, src, dst, t);
@@ -488,9 +517,39 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
     const int t = c->steps_done;
     int depth = 1;
     const bool any_face = strip_logic && (face_south(c) || face_north(c));
+    c->deep_now = false;
     if (c->fuse > 1) {
         const int room = remaining - (c->trailing_pair ? 0 : 1);       // iterations a fused launch may take now
         int dmax = std::min(c->fuse, (any_face || c->slide) ? 3 : 4);  // (four: k_step4_tile, no faces)
+        // a deep plan: D iterations while D fit, then the four-/three-/two-iteration tile kernels for what is left
+        const int deep = (!any_face && !c->slide && c->deep) ? deep_depth(c->deep) : 0;
+        if (deep) {
+            bool ok = room >= deep;
+            for (int j = 1; j < deep; ++j) ok = ok && !(of > 0 && (t + j) % of == 0);
+            dmax = std::min(4, deep - 1);
+            if (ok && of <= 0 && room < 3 * deep && room % deep != 0) {
+                // The tail of a call whose length is no multiple of the depth: 20 = 6 + 6 + 4 + 4 costs less than
+                // 6 + 6 + 6 + 2 (the two- and one-iteration kernels run at half and a third of the fused rate). Cheapest
+                // split of `room` into launches of depth D, 4, 3, 2, 1 (relative cost per iteration from the measurements).
+                static const double per_it[5] = {2.8, 1.6, 1.12, 1.08, 1.0};     // depth 1, 2, 3, 4, D
+                double best[64];
+                int first[64];
+                best[0] = 0.0; first[0] = 0;
+                for (int r = 1; r <= room; ++r) {
+                    best[r] = 1e30; first[r] = 1;
+                    const int opts[5] = {1, 2, 3, 4, deep};
+                    for (int k = 0; k < 5; ++k) {
+                        const int d = opts[k];
+                        if (d > r || (k < 4 && d > dmax)) continue;
+                        const double cst = best[r - d] + per_it[k] * d;
+                        if (cst < best[r] - 1e-12) { best[r] = cst; first[r] = d; }
+                    }
+                }
+                if (first[room] == deep) depth = deep;
+                else { ok = false; dmax = first[room]; }
+            } else if (ok) depth = deep;
+        }
+        c->deep_now = depth > 1 && depth == deep;
         // A three-iteration plan leaves a one- or two-iteration launch at the end of a call whose length is not a
         // multiple of three, which runs at half the rate. Where the four-iteration kernel is usable, one (remainder 1)
         // or two (remainder 2) four-iteration launches absorb it: 20 = 4 + 4 + 3 + 3 + 3 + 3.
@@ -690,13 +749,14 @@ inline int alloc_buffers(lbm_ctx* c) {
 // 4096x1024 fp64 depending on the allocation). All candidates compute bit-identical results, so lbm_initialise
 // times each one on the real buffers (12 warm-up iterations, then the faster of two 36-iteration windows) and keeps the fastest together
 // with the very allocation it was measured on.
-struct Plan { int layout, variant, nt, alternate, fuse, ty, xcd; const char* name; int slide = 0; };
+struct Plan { int layout, variant, nt, alternate, fuse, ty, xcd; const char* name; int slide = 0; int deep = 0; };
 
 inline void apply_plan(lbm_ctx* c, const Plan& pl) {
     configure_layout(c, pl.layout);
     c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate; c->fuse = pl.fuse > 0 ? pl.fuse : 1; c->xcd = pl.xcd;
     if (pl.ty) c->pair_ty = pl.ty;
     c->slide = pl.slide;
+    c->deep = pl.deep;
     if (c->slide && c->total * c->esize >= (size_t(1) << 32)) {   // k_step_slide addresses a buffer with 32-bit byte offsets
         c->slide = 0;
     }
@@ -736,9 +796,11 @@ template <typename T>
 int choose_plan(lbm_ctx* c) {
     const bool strips = (c->comm && c->nranks > 1) || c->group_n > 1 || c->loopback;
     const Plan fixed = {(strips || c->loopback) ? 1 : c->layout, c->variant, c->use_nt, c->alternate, c->fuse, c->pair_ty, c->xcd,
-                        "fixed by options", c->slide};
+                        "fixed by options", c->slide, c->deep};
     std::vector<Plan> cand;
     const bool vec_ok = (c->nx % vec_width<T>() == 0), p2 = pair_possible(c);
+    // "small": 1024-cell tiles make at most two rounds of one block per CU (fp32: two blocks per CU)
+    const bool small_grid = (size_t)c->nx * c->nyl <= (size_t)2048 * c->num_cus * (c->esize == 4 ? 2 : 1);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     configure_layout(c, 1);
@@ -762,6 +824,13 @@ int choose_plan(lbm_ctx* c) {
             cand.push_back({1, 1, 0, 1, f, 12, 1, "row-interleaved/3-step 64x12/alternate/xcd"});
         } else {
             if (p2) cand.push_back({1, 1, 1, 0, 4, 8, 1, "row-interleaved/4-step 64x8/nt-store/xcd"});
+            cand.push_back({1, 1, 1, 0, 5, 12, 1, "row-interleaved/5-step 32x16/nt-store/xcd", 0, 4});   // two 512-thread blocks per CU (fp64)
+            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 32x16/nt-store/xcd", 0, 5});
+            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x16/nt-store/xcd", 0, 1});
+            if (small_grid) {   // one round of LDS-filling tiles: a launch's load and store phases are paid once per 7-8 iterations
+                cand.push_back({1, 1, 1, 0, 7, 12, 1, "row-interleaved/7-step 64x16/nt-store/xcd", 0, 2});
+                cand.push_back({1, 1, 1, 0, 8, 12, 1, "row-interleaved/8-step 32x32/nt-store/xcd", 0, 3});
+            }
             if (p2) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step sliding 64-column/nt-store", 1});
             if (p2) cand.push_back({1, 1, 0, 0, 3, 12, 1, "row-interleaved/3-step sliding 64-column", 1});
             if (p2) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
@@ -773,6 +842,7 @@ int choose_plan(lbm_ctx* c) {
         }
         if (!strips) {
             if (p2) cand.push_back({0, 0, 1, 0, 4, 8, 1, "planar/4-step 64x8/nt-store/xcd"});
+            cand.push_back({0, 0, 1, 0, 5, 12, 1, "planar/5-step 32x16/nt-store/xcd", 0, 4});
             if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 1, "planar/3-step sliding 64-column/nt-store", 1});
             if (p2) cand.push_back({0, 0, 0, 0, 3, 12, 1, "planar/3-step sliding 64-column", 1});
             if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 1, "planar/3-step 64x12/nt-store/xcd"});
@@ -1684,18 +1754,24 @@ int lbm_load_state(lbm_ctx* c, const char* path) {
 int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     if (!c || !key) return fail(LBM_ERR_ARG, "null argument");
     const std::string k(key);
-    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune" || k == "pair" || k == "fuse" || k == "pair_ty" || k == "loopback" || k == "slide" || k == "arith"))
+    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune" || k == "pair" || k == "fuse" || k == "pair_ty" || k == "loopback" || k == "slide" || k == "deep" || k == "arith"))
         return fail(LBM_ERR_ARG, "option %s must be set before lbm_initialise", key);
     if (k == "variant") c->variant = (int)value;
     else if (k == "timing") c->timing = (int)value;
     else if (k == "alternate") c->alternate = (int)value;
     else if (k == "layout") c->layout = (int)value ? 1 : 0;
     else if (k == "nt") c->use_nt = (int)value ? 1 : 0;
-    else if (k == "fuse") { if (value < 1 || value > 4) return fail(LBM_ERR_ARG, "fuse must be 1, 2, 3 or 4 (4: tile kernel, no strip faces)"); c->fuse = (int)value; }
+    else if (k == "fuse") { if (value < 1 || value > 4) return fail(LBM_ERR_ARG, "fuse must be 1, 2, 3 or 4 (4: tile kernel, no strip faces)"); c->fuse = (int)value; c->deep = 0; }
+    else if (k == "deep") {     // k_stepd_tile: 1: 6 iterations on 64x16 tiles, 2: 7 on 64x16, 3: 8 on 32x32 (1024 threads);
+                                // 4 / 5: 5 / 6 iterations on 32x16 tiles (512 threads). Whole-domain launches only.
+        if (value < 0 || value > 5) return fail(LBM_ERR_ARG, "deep must be 0..5");
+        c->deep = (int)value;
+        if (c->deep) { c->fuse = deep_depth(c->deep); c->slide = 0; }
+    }
     else if (k == "pair") c->fuse = (int)value ? 2 : 1;
     else if (k == "trailing_pair") c->trailing_pair = (int)value ? 1 : 0;
     else if (k == "xcd") c->xcd = (int)value ? 1 : 0;
-    else if (k == "slide") c->slide = (int)value ? 1 : 0;
+    else if (k == "slide") { c->slide = (int)value ? 1 : 0; if (c->slide) c->deep = 0; }
     else if (k == "arith") { if (value != 0 && value != 1) return fail(LBM_ERR_ARG, "arith must be 0 (strict) or 1 (contracted)"); c->arith = (int)value; }
     else if (k == "deep_halo") { c->deep_halo = (int)value ? 1 : 0; c->deep_pinned = true; }
     else if (k == "skip_exchange") c->skip_exchange = (int)value ? 1 : 0;
@@ -1740,7 +1816,8 @@ const char* lbm_kernel_name(const lbm_ctx* c) {
     const char* t = c->p.precision == LBM_PRECISION_F32 ? "float" : "double";
     const char* nt = c->use_nt ? "true" : "false";
     const int ar = c->arith;
-    if (c->fuse > 1 && c->slide) snprintf(name, sizeof(name), "k_step_slide<%s,%d,6,%s,%d>", t, c->fuse, nt, ar);
+    if (c->fuse > 2 && c->deep) snprintf(name, sizeof(name), "k_stepd_tile<%s,%s,%d,%s,true,%d>", t, deep_tile(c->deep), deep_depth(c->deep), nt, ar);
+    else if (c->fuse > 1 && c->slide) snprintf(name, sizeof(name), "k_step_slide<%s,%d,6,%s,%d>", t, c->fuse, nt, ar);
     else if (c->fuse == 4) snprintf(name, sizeof(name), "k_step4_tile<%s,8,%d,%s,%s,%d>", t, c->esize == 8 ? 1024 : 512, nt, c->xcd ? "true" : "false", ar);
     else if (c->fuse > 1) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%s,%s,%d>", c->fuse, t, c->pair_ty,
                                    c->pair_ty == 12 ? (c->fuse == 3 ? 1024 : 768) : 512, nt, c->xcd ? "true" : "false", ar);

@@ -39,6 +39,7 @@
 //     store P_{t+1}
 // Algorithmic traffic: 9 loads + 9 stores per lattice update = 144 B (fp64) / 72 B (fp32). HBM-bound; no MFMA.
 #pragma once
+#include <utility>
 #include <hip/hip_runtime.h>
 
 namespace lbmk {
@@ -156,6 +157,27 @@ __device__ __forceinline__ float recip_t(float d) {        // v_rcp_f32 (1 ulp) 
     return fma_t(fma_t(-d, r, 1.0f), r, r);
 }
 
+// Buffer-descriptor access for the block-uniform "lean" paths: address = descriptor base + SGPR offset + ONE 32-bit VGPR
+// offset, so the nine populations of a cell cost nine scalar adds and no vector address arithmetic at all (a global_load
+// needs a vector add per population: the plane / row displacements are far beyond its immediate-offset range).
+typedef unsigned lbm_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_desc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000);   // raw, no range limit
+}
+template <typename T> __device__ __forceinline__ T buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ double buf_load<double>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+template <> __device__ __forceinline__ float buf_load<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+template <bool NT> __device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(lbm_u32x2, v), r, voff, soff, NT ? 2 : 0);   // aux 2 = nt
+}
+template <bool NT> __device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, NT ? 2 : 0);
+}
+
 // collision_step for one cell, LBMSolver.h:101-123 (moments i = 0..8 ascending from 0, N7).
 template <typename T, int AR = AR_STRICT>
 __device__ __forceinline__ void bgk_collide(T (&f)[Q], T tau_inv) {
@@ -167,22 +189,23 @@ __device__ __forceinline__ void bgk_collide(T (&f)[Q], T tau_inv) {
         rho = ((f[0] + a13) + (a24 + a57)) + a68;
         ux = (d13 + d57) - d68;
         uy = (d24 + d57) + d68;
-        const T inv = recip_t(rho);
-        ux *= inv;
-        uy *= inv;
-        const T base = fma_t(T(-1.5), fma_t(ux, ux, uy * uy), T(1.0));      // 1 - 1.5 u^2
+        // v = 3u. 1 + 3cu + 4.5cu^2 - 1.5u^2 = base + cv*(1 + 0.5cv) with cv = c.v and base = 1 - v^2/6: the inner bracket
+        // is one FMA with INLINE constants (0.5, 1.0). gfx950 VALU instructions take one SGPR/literal operand at most, so
+        // fma(4.5, cu, 3.0) cost two v_mov per direction to build the 3.0 — 16 of ~100 vector instructions per cell.
+        const T inv3 = recip_t(rho) * T(3.0);
+        const T vx = ux * inv3, vy = uy * inv3;
+        const T base = fma_t(T(-1.0 / 6.0), fma_t(vx, vx, vy * vy), T(1.0));
         const T wr0 = wgt<T>(0) * rho, wr1 = wgt<T>(1) * rho, wr5 = wgt<T>(5) * rho;
 #pragma unroll
         for (int i = 0; i < Q; ++i) {
-            T cu;
-            if (cx(i) == 0 && cy(i) == 0) cu = T(0);
-            else if (cy(i) == 0) cu = T(cx(i)) * ux;
-            else if (cx(i) == 0) cu = T(cy(i)) * uy;
-            else cu = T(cx(i)) * ux + T(cy(i)) * uy;
-            // 1 + 3cu + 4.5cu^2 - 1.5u^2 = base + cu*(3 + 4.5cu);  f - (f - feq)/tau = f + (feq - f)/tau
-            const T t = (i == 0) ? base : fma_t(cu, fma_t(T(4.5), cu, T(3.0)), base);
+            T cv;
+            if (cx(i) == 0 && cy(i) == 0) cv = T(0);
+            else if (cy(i) == 0) cv = T(cx(i)) * vx;
+            else if (cx(i) == 0) cv = T(cy(i)) * vy;
+            else cv = T(cx(i)) * vx + T(cy(i)) * vy;
+            const T t = (i == 0) ? base : fma_t(cv, fma_t(cv, T(0.5), T(1.0)), base);
             const T wr = i == 0 ? wr0 : (i < 5 ? wr1 : wr5);
-            f[i] = fma_t(tau_inv, fma_t(wr, t, -f[i]), f[i]);
+            f[i] = fma_t(tau_inv, fma_t(wr, t, -f[i]), f[i]);     // f - (f - feq)/tau = f + (feq - f)/tau
         }
         return;
     }
@@ -211,12 +234,22 @@ __device__ __forceinline__ void bgk_collide(T (&f)[Q], T tau_inv) {
     }
 }
 
+// Grid::check_stability on one cell's populations: NaN, Inf, > 1e5, < -1e5 (LBMGrid.h:296-307); 1e5 is exact in fp32 too,
+// so the test is done in T. Filter first: bit 30 of an IEEE word (the top exponent bit) is set iff |f| >= 2 or f is
+// Inf/NaN, so the OR of the nine (high) words has it clear iff every |f_i| < 2 — four v_or3_b32 and a test instead of nine
+// compares; the exact test runs only for a wave that holds such a value (never, in a healthy flow). Same verdict, bit for bit.
+__device__ __forceinline__ unsigned exp_word(double v) { return (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32); }
+__device__ __forceinline__ unsigned exp_word(float v) { return __builtin_bit_cast(unsigned, v); }
 template <typename T>
 __device__ __forceinline__ bool any_unstable(const T (&f)[Q]) {
-    bool bad = false;
+    unsigned o = 0;
 #pragma unroll
-    for (int i = 0; i < Q; ++i) bad |= !(fabs(f[i]) <= T(1e5));   // NaN, Inf, > 1e5, < -1e5 (LBMGrid.h:296-307); 1e5 is
-                                                                   // exact in fp32 too, so the test is done in T
+    for (int i = 0; i < Q; ++i) o |= exp_word(f[i]);
+    bool bad = false;
+    if (o & 0x40000000u) {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) bad |= !(fabs(f[i]) <= T(1e5));
+    }
     return bad;
 }
 
@@ -463,9 +496,9 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
     const bool lean = !near_cyl && X0 >= 3 && X0 + TX + 2 <= a.nx - 1 && yg0 >= 3 && yg0 + TY + 2 <= a.ny_glob - 1 &&
                       Y0 + TY <= y_end && e.small;
     // (lean path) one uniform base per buffer + a 32-bit byte offset per access: a vector add per plane instead of a 64-bit one
-    const char* const sbase = reinterpret_cast<const char*>(a.src);
-    char* const dbase = reinterpret_cast<char*>(a.dst);
     const unsigned pitchB = (unsigned)a.pitch * (unsigned)sizeof(T), planeB = (unsigned)a.plane * (unsigned)sizeof(T);
+    const unsigned KB = pitchB + (unsigned)sizeof(T);   // the source descriptor starts KB bytes early: every scalar offset stays >= 0
+    const __amdgpu_buffer_rsrc_t rsrc = buf_desc(reinterpret_cast<const char*>(a.src) - KB), rdst = buf_desc(a.dst);
     auto run = [&]<bool LEAN>() {
         bool bad = false;
 #pragma unroll
@@ -485,10 +518,11 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
             }
             if (inside) {
                 if (LEAN) {
-                    const unsigned c = (unsigned)(y + GR) * pitchB + (unsigned)(a.xoff + x) * (unsigned)sizeof(T);
+                    const unsigned ub = (unsigned)(Y0 - 2 + GR) * pitchB + (unsigned)(a.xoff + X0 - 2) * (unsigned)sizeof(T) + KB;   // block-uniform
+                    const unsigned voff = (unsigned)ry * pitchB + (unsigned)rx * (unsigned)sizeof(T);
 #pragma unroll
                     for (int i = 0; i < Q; ++i)
-                        f[i] = *reinterpret_cast<const T*>(sbase + (c + (unsigned)i * planeB - (unsigned)cy(i) * pitchB - (unsigned)(cx(i) * (int)sizeof(T))));
+                        f[i] = buf_load<T>(rsrc, voff, ub + (unsigned)i * planeB - (unsigned)cy(i) * pitchB - (unsigned)(cx(i) * (int)sizeof(T)));
                 } else {
                     const long c = (long)(y + GR) * a.pitch + a.xoff + x;
 #pragma unroll
@@ -591,12 +625,10 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
             }
             bgk_collide<T, AR>(f, a.tau_inv);
             if (LEAN) {
-                const unsigned c = (unsigned)(y + GR) * pitchB + (unsigned)(a.xoff + x) * (unsigned)sizeof(T);
+                const unsigned ub = (unsigned)(Y0 + GR) * pitchB + (unsigned)(a.xoff + X0) * (unsigned)sizeof(T);
+                const unsigned voff = (unsigned)ly * pitchB + (unsigned)lx * (unsigned)sizeof(T);
 #pragma unroll
-                for (int i = 0; i < Q; ++i) {
-                    T* p = reinterpret_cast<T*>(dbase + (c + (unsigned)i * planeB));
-                    if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
-                }
+                for (int i = 0; i < Q; ++i) buf_store<NT>(f[i], rdst, voff, ub + (unsigned)i * planeB);
             } else {
                 const long c = (long)(y + GR) * a.pitch + a.xoff + x;
 #pragma unroll
@@ -638,8 +670,12 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs
     // LEAN (block-uniform): tile + three rings strictly inside the domain, full tile, nothing near the cylinder
     const int yg0 = a.y_start + Y0;
     const bool lean = !near_cyl && X0 >= HW + 1 && X0 + TX + HW <= a.nx - 1 && yg0 >= HW + 1 && yg0 + TY + HW <= a.ny_glob - 1 &&
-                      Y0 + TY <= y_end;
+                      Y0 + TY <= y_end && e.small;
     // one cell: BCs, stability, collision (solid cells keep w_i); `count` = the cell's instability is reported
+    // (lean path) buffer descriptors: nine scalar offsets + one vector offset per cell (see buf_load)
+    const unsigned pitchB = (unsigned)a.pitch * (unsigned)sizeof(T), planeB = (unsigned)a.plane * (unsigned)sizeof(T);
+    const unsigned KB = pitchB + (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rsrc = buf_desc(reinterpret_cast<const char*>(a.src) - KB), rdst = buf_desc(a.dst);
     auto update = [&](T (&f)[Q], int x, int yg, bool count, bool& bad) {
         if (lean) {                                 // block-uniform
             bad |= any_unstable(f);
@@ -665,7 +701,14 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs
         const int yg = a.y_start + y;
         const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
         T f[Q];
-        if (!(row_in && col_in) || y > y_end + HW - 1) {
+        if (lean) {                                                       // block-uniform
+            const unsigned ub = (unsigned)(Y0 - HW + GR) * pitchB + (unsigned)(a.xoff + X0 - HW) * (unsigned)sizeof(T) + KB;
+            const unsigned voff = (unsigned)ry * pitchB + (unsigned)rx * (unsigned)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < Q; ++i)
+                f[i] = buf_load<T>(rsrc, voff, ub + (unsigned)i * planeB - (unsigned)cy(i) * pitchB - (unsigned)(cx(i) * (int)sizeof(T)));
+            update(f, x, yg, true, bad);
+        } else if (!(row_in && col_in) || y > y_end + HW - 1) {
 #pragma unroll
             for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
         } else {
@@ -705,7 +748,7 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs
             const int yg = a.y_start + y;
             const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
             T f[Q];
-            if (!(row_in && col_in)) {
+            if (!lean && !(row_in && col_in)) {
 #pragma unroll
                 for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
             } else {
@@ -730,6 +773,15 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs
         T f[Q];
 #pragma unroll
         for (int i = 0; i < Q; ++i) f[i] = lds[i][ly + HW - cy(i)][lx + HW - cx(i)];
+        if (lean) {                                                       // block-uniform
+            bad |= any_unstable(f);
+            bgk_collide<T, AR>(f, a.tau_inv);
+            const unsigned ub = (unsigned)(Y0 + GR) * pitchB + (unsigned)(a.xoff + X0) * (unsigned)sizeof(T);
+            const unsigned voff = (unsigned)ly * pitchB + (unsigned)lx * (unsigned)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < Q; ++i) buf_store<NT>(f[i], rdst, voff, ub + (unsigned)i * planeB);
+            continue;
+        }
         const bool solid = near_cyl && is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
         T rho_bc, u_out;
         if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
@@ -744,6 +796,172 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs
         }
     }
     if (bad) atomicMin(a.unstable_t, a.t + 3);
+}
+
+// D iterations per launch (D = 5..8) on a TX x TY tile: k_step4_tile generalised — level 1 from HBM into an LDS image of the
+// (TX + 2(D-1)) x (TY + 2(D-1)) region, levels 2..D-1 in place (pull into registers, barrier, compute, overwrite, barrier),
+// level D the tile -> HBM. Two regimes use it (the plan measurement picks the shape):
+//   32x16 tiles, 512 threads, D = 5/6 (69 / 79 KB of LDS in fp64: TWO blocks per CU). With three iterations per launch
+//     the step is within 20 % of what HBM delivers; deeper fusion removes that bound but an LDS image that fills the CU
+//     leaves ONE block per CU, whose waves then all sit in the same phase (LDS pull, barrier, arithmetic, LDS write,
+//     barrier): VALU and LDS take turns instead of overlapping. Two half-size blocks per CU are two independent barrier
+//     groups that fill each other's gaps: 122 GLUPS at 4096x1024 fp64 against 104 (one 64x16 block) and 112 (k_step4_tile).
+//   64x16 / 32x32 tiles, 1024 threads, D = 6..8: grids so small that one launch is a single round of blocks. There the
+//     chip runs load -> compute -> store in lockstep, so the two memory phases are paid per LAUNCH: fusing more
+//     iterations divides them, at the price of ~1.5x redundant collisions that such a grid has VALU time to spare for.
+// Whole-domain launches only (rows outside the domain hold the permanent ghost values; a strip's ghost rows go GR = 6 deep).
+// waves per SIMD the register allocation may assume: as many blocks as the LDS image allows on a CU (at most 32 waves)
+template <typename T, int TX, int TY, int D>
+constexpr int deep_waves_per_simd() {
+    const int lds = (int)sizeof(T) * Q * (TX + 2 * (D - 1)) * (TY + 2 * (D - 1)), waves = TX * TY / 64;
+    int blocks = 160 * 1024 / lds;
+    if (blocks * waves > 32) blocks = 32 / waves;
+    return (blocks * waves) / 4 > 0 ? (blocks * waves) / 4 : 1;
+}
+template <typename T, int TX, int TY, int D, bool NT, bool XCD, int AR = AR_STRICT>
+__global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())) k_stepd_tile(const KArgs<T> a, const K2Extra<T> e) {
+    constexpr int NTH = TX * TY, HW = D - 1, R1W = TX + 2 * HW, R1H = TY + 2 * HW, LP = R1W;
+    static_assert(D >= 3 && (NTH == 1024 || NTH == 512 || NTH == 256), "one tile cell per thread at the last level");
+    static_assert((size_t)Q * R1H * LP * sizeof(T) <= 160 * 1024, "level-1 region must fit the CU's LDS");
+    __shared__ T lds[Q][R1H][LP];
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (XCD) {
+        const int nb = gridDim.x * gridDim.y;
+        int b = by * gridDim.x + bx;
+        if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;
+        by = b / gridDim.x; bx = b - by * gridDim.x;
+    }
+    if (a.reverse) by = (int)gridDim.y - 1 - by;
+    const int X0 = bx * TX;
+    int y_end;
+    const int Y0 = band_origin(a, by, TY, y_end);
+    const bool near_cyl = tile_near_cylinder(a, X0, Y0, TX, TY, HW);
+    auto outside_value = [&](bool row_in, bool col_in, int i) -> T { return (row_in && !col_in) ? T(0) : e.feq_in[i]; };
+    const int yg0 = a.y_start + Y0;
+    const bool lean = !near_cyl && X0 >= HW + 1 && X0 + TX + HW <= a.nx - 1 && yg0 >= HW + 1 && yg0 + TY + HW <= a.ny_glob - 1 &&
+                      Y0 + TY <= y_end && e.small;
+    // (lean path) buffer descriptors: nine scalar offsets + one vector offset per cell (see buf_load)
+    const unsigned pitchB = (unsigned)a.pitch * (unsigned)sizeof(T), planeB = (unsigned)a.plane * (unsigned)sizeof(T);
+    const unsigned KB = pitchB + (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rsrc = buf_desc(reinterpret_cast<const char*>(a.src) - KB), rdst = buf_desc(a.dst);
+    auto update = [&](T (&f)[Q], int x, int yg, bool count, bool& bad) {
+        if (lean) {                                 // block-uniform
+            bad |= any_unstable(f);
+            bgk_collide<T, AR>(f, a.tau_inv);
+            return;
+        }
+        bool solid = false;
+        if (near_cyl) solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);   // block-uniform branch
+        T rho_bc, u_out;
+        if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+        if (count) bad |= any_unstable(f);
+        bgk_collide<T, AR>(f, a.tau_inv);
+        if (near_cyl) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
+        }
+    };
+    bool bad = false;
+#pragma unroll
+    for (int r = threadIdx.x; r < R1W * R1H; r += NTH) {                 // level 1 on region 1: iteration t
+        const int ry = r / R1W, rx = r - ry * R1W;
+        const int x = X0 + rx - HW, y = Y0 + ry - HW;
+        const int yg = a.y_start + y;
+        const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+        T f[Q];
+        if (lean) {                                                       // block-uniform
+            const unsigned ub = (unsigned)(Y0 - HW + GR) * pitchB + (unsigned)(a.xoff + X0 - HW) * (unsigned)sizeof(T) + KB;
+            const unsigned voff = (unsigned)ry * pitchB + (unsigned)rx * (unsigned)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < Q; ++i)
+                f[i] = buf_load<T>(rsrc, voff, ub + (unsigned)i * planeB - (unsigned)cy(i) * pitchB - (unsigned)(cx(i) * (int)sizeof(T)));
+            update(f, x, yg, true, bad);
+        } else if (!(row_in && col_in) || y > y_end + HW - 1) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
+        } else {
+            const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
+            update(f, x, yg, true, bad);
+        }
+#pragma unroll
+        for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
+    }
+    if (bad) atomicMin(a.unstable_t, a.t);
+    __syncthreads();
+    auto in_place = [&]<int L>() {                                        // level L on region L = region 1 shrunk by L-1 rings
+        constexpr int O = L - 1, RW = R1W - 2 * O, RH = R1H - 2 * O, CPT = (RW * RH + NTH - 1) / NTH;
+        T g[CPT][Q];
+        int cell[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int r = (int)threadIdx.x + k * NTH;
+            cell[k] = (r < RW * RH) ? r : -1;
+            if (cell[k] >= 0) {
+                const int ry = r / RW + O, rx = r - (r / RW) * RW + O;
+#pragma unroll
+                for (int i = 0; i < Q; ++i) g[k][i] = lds[i][ry - cy(i)][rx - cx(i)];
+            }
+        }
+        __syncthreads();
+        bool badl = false;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            if (cell[k] < 0) continue;
+            const int r = cell[k];
+            const int ry = r / RW + O, rx = r - (r / RW) * RW + O;
+            const int x = X0 + rx - HW, y = Y0 + ry - HW;
+            const int yg = a.y_start + y;
+            const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+            T f[Q];
+            if (!lean && !(row_in && col_in)) {
+#pragma unroll
+                for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
+            } else {
+#pragma unroll
+                for (int i = 0; i < Q; ++i) f[i] = g[k][i];
+                update(f, x, yg, y <= y_end + HW - L, badl);
+            }
+#pragma unroll
+            for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
+        }
+        if (badl) atomicMin(a.unstable_t, a.t + L - 1);
+        __syncthreads();
+    };
+    [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (in_place.template operator()<Ls + 2>(), ...); }(std::make_integer_sequence<int, D - 2>{});
+    bad = false;
+    {                                                                     // level D on the tile: iteration t+D-1
+        const int o = threadIdx.x;
+        const int ly = o / TX, lx = o - ly * TX;
+        const int x = X0 + lx, y = Y0 + ly;
+        if (y < y_end && x < a.nx) {
+            const int yg = a.y_start + y;
+            T f[Q];
+#pragma unroll
+            for (int i = 0; i < Q; ++i) f[i] = lds[i][ly + HW - cy(i)][lx + HW - cx(i)];
+            const bool solid = !lean && near_cyl && is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+            T rho_bc, u_out;
+            if (!lean && !solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+            bad |= any_unstable(f);
+            if (lean) {                                                   // block-uniform
+                bgk_collide<T, AR>(f, a.tau_inv);
+                const unsigned ub = (unsigned)(Y0 + GR) * pitchB + (unsigned)(a.xoff + X0) * (unsigned)sizeof(T);
+                const unsigned voff = (unsigned)ly * pitchB + (unsigned)lx * (unsigned)sizeof(T);
+#pragma unroll
+                for (int i = 0; i < Q; ++i) buf_store<NT>(f[i], rdst, voff, ub + (unsigned)i * planeB);
+            } else if (!solid) {
+                bgk_collide<T, AR>(f, a.tau_inv);
+                const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+#pragma unroll
+                for (int i = 0; i < Q; ++i) {
+                    T* p = a.dst + (long)i * a.plane + c;
+                    if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
+                }
+            }
+        }
+    }
+    if (bad) atomicMin(a.unstable_t, a.t + D - 1);
 }
 
 // D iterations per launch with a SLIDING WINDOW in y (temporal blocking without y-overlap). A block owns a column of

@@ -46,6 +46,14 @@ PLANS = {
     "planar-slide3-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=3, slide=1),
     "rowil-slide3": dict(tune=0, layout=1, variant=1, nt=0, alternate=1, fuse=3, slide=1),
     "rowil-slide2-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=2, slide=1),
+    # six / seven / eight iterations per launch on an LDS-filling tile (k_stepd_tile; what a small grid's measurement picks);
+    # calls whose length is no multiple of the depth finish with the four-/three-/two-iteration tile kernels
+    "rowil-deep6-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=1),
+    "planar-deep7-alt": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, pair_ty=8, xcd=0, deep=2),
+    "rowil-deep8-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=3),
+    # five / six iterations per launch on 32x16 tiles with 512-thread blocks (two per CU in fp64: what a large grid's measurement picks)
+    "rowil-half5-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=4),
+    "planar-half6": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=5),
     # contracted collision arithmetic (option "arith" 1: FMA + one reciprocal, what the reference's -ffast-math -mfma build
     # permits): not bit-identical to the strict oracle, held to the north-star tolerance 1e-10 like every other plan
     "fast-auto": dict(arith=1),
@@ -56,6 +64,9 @@ PLANS = {
     "fast-rowil-fuse3-12-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
     "fast-planar-pair8": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, pair=1, pair_ty=8, arith=1),
     "fast-rowil-fuse4-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
+    "fast-rowil-deep7": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=2, arith=1),
+    "fast-rowil-half5": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=4, arith=1),
+    "fast-planar-deep8": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=3, arith=1),
 }
 FAST = [k for k, v in PLANS.items() if v and v.get("arith")]
 
@@ -69,6 +80,8 @@ def fused_depth(plan_opts, steps_left, done, of):
     """The depth the library picks for the next launch (lbm_hip.hip: advance) when it is asked for exactly that many
     iterations with trailing_pair=1 — the host-staged strip drivers below must issue ONE launch per lbm_step call."""
     maxd = (plan_opts or {}).get("fuse", 2 if (plan_opts or {}).get("pair") else 1)
+    if (plan_opts or {}).get("deep"):
+        maxd = 3                                     # a strip has faces: the deep kernel is not used there
     for d in (3, 2):
         if d <= maxd and steps_left >= d + 1 and all(of <= 0 or (done + j) % of != 0 for j in range(1, d)):
             return d

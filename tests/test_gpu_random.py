@@ -1,6 +1,6 @@
 """Seeded random sweep of the parameter space: grid sizes (ragged, tiny, one tile column, many), tau, inlet velocity,
 cylinder position/radius (inside, on the inlet, on a wall, on a corner, absent, covering the outlet), fusion depth,
-kernel family (tile / sliding window), layout, store policy, collision arithmetic and — where the grid is tall enough —
+kernel family (tile / sliding window / deep tile), layout, store policy, collision arithmetic and — where the grid is tall enough —
 an in-process group of strips with a random exchange schedule. Every case is compared with the CPU oracle: strict
 arithmetic populations bit for bit, contracted arithmetic within 1e-10; rho/u and forces to 1e-10 either way.
 """
@@ -52,15 +52,36 @@ def cases(n=36, seed=20260104):
             opts.update(layout=1, overlap=int(rng.integers(0, 3)), deep_halo=int(rng.integers(0, 2)),
                         group_threads=int(rng.integers(0, 2)))
         out.append((k, nx, ny, tau, u, cx, cy, cr, steps, of, opts, strips))
+    # deep tile kernel (6/7/8 iterations per launch): grids from one partial tile to several tiles per direction
+    for k in range(2 * n, 2 * n + 40):
+        nx = int(rng.choice([rng.integers(2, 40), rng.integers(40, 200), rng.integers(200, 500), 64, 128, 32, 33, 65, 96]))
+        ny = int(rng.choice([rng.integers(2, 12), rng.integers(12, 60), rng.integers(60, 140), 16, 17, 32, 33, 48, 64]))
+        tau = float(rng.uniform(0.56, 1.2))
+        u = float(rng.uniform(0.005, 0.09))
+        cyl = rng.integers(0, 6)
+        cx, cy, cr = [(0.2, 0.5, 0.05), (-1.0, 0.5, 0.0), (0.0, 0.5, 0.15), (0.5, 0.0, 0.2), (0.0, 0.0, 0.3), (0.98, 0.5, 0.25)][cyl]
+        cx += float(rng.uniform(-0.02, 0.02)) if cyl not in (1,) else 0.0
+        steps = int(rng.integers(1, 120))
+        of = int(rng.integers(1, 40))
+        deep = int(rng.integers(1, 6))                 # 1..3: 1024-thread shapes, 4/5: 512-thread shapes
+        opts = dict(tune=0, layout=int(rng.integers(0, 2)), variant=int(rng.integers(0, 2)), nt=int(rng.integers(0, 2)),
+                    alternate=int(rng.integers(0, 2)), pair_ty=int(rng.choice([8, 12])), xcd=int(rng.integers(0, 2)),
+                    deep=deep, arith=int(rng.integers(0, 2)), fuse=[0, 6, 7, 8, 5, 6][deep])     # ("fuse" is only the label here: set below)
+        strips = int(rng.integers(1, 3)) if ny >= 36 and k % 4 == 0 else 1       # with faces the library falls back to three
+        if strips > 1:
+            opts.update(layout=1, overlap=int(rng.integers(0, 3)), deep_halo=int(rng.integers(0, 2)))
+        out.append((k, nx, ny, tau, u, cx, cy, cr, steps, of, opts, strips))
     return out
 
 
-@pytest.mark.parametrize("case", cases(), ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-f{c[10]['fuse']}" + ("s" if c[10].get("slide") else "")
+@pytest.mark.parametrize("case", cases(), ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-f{c[10]['fuse']}" + ("s" if c[10].get("slide") else "") + ("d" if c[10].get("deep") else "")
                          + ("-fast" if c[10].get("arith") else "") + (f"-{c[11]}strips" if c[11] > 1 else ""))
 def test_random_case_matches_oracle(case):
     from oracle.oracle import Oracle, make_params
     lbm = importlib.import_module(PKG)
     k, nx, ny, tau, u, cx, cy, cr, steps, of, opts, strips = case
+    if opts.get("deep"):
+        opts = {key: v for key, v in opts.items() if key != "fuse"}     # "deep" sets the depth itself
     strict = not opts.get("arith")
     kw = dict(tau=tau, inlet_velocity=u, cylinder_x=cx, cylinder_y=cy, cylinder_radius=cr)
     o = Oracle(make_params(nx, ny, **kw))

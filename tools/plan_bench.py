@@ -39,6 +39,17 @@ PLANS = {
     "tile4": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1),
     "fast-tile4": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
     "fast-tile4-planar": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
+    "fast-deep6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=1, arith=1),
+    "fast-deep7": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=2, arith=1),
+    "fast-deep8": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=3, arith=1),
+    "fast-half5": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=4, arith=1),
+    "fast-half6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=5, arith=1),
+    "fast-half5-planar": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, pair_ty=12, xcd=1, deep=4, arith=1),
+    "fast-half5-nt0": dict(tune=0, layout=1, variant=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=4, arith=1),
+    "half5": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=4),
+    "half6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=5),
+    "deep7": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=2),
+    "deep8": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=3),
     "fast-auto": dict(arith=1),
     "fast-site": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1, arith=1),
     "fast-vec": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=1, arith=1),
