@@ -844,12 +844,8 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
     const unsigned pitchB = (unsigned)a.pitch * (unsigned)sizeof(T), planeB = (unsigned)a.plane * (unsigned)sizeof(T);
     const unsigned KB = pitchB + (unsigned)sizeof(T);
     const __amdgpu_buffer_rsrc_t rsrc = buf_desc(reinterpret_cast<const char*>(a.src) - KB), rdst = buf_desc(a.dst);
+    // one general cell: BCs, stability, collision (solid cells keep w_i); `count` = the cell's instability is reported
     auto update = [&](T (&f)[Q], int x, int yg, bool count, bool& bad) {
-        if (lean) {                                 // block-uniform
-            bad |= any_unstable(f);
-            bgk_collide<T, AR>(f, a.tau_inv);
-            return;
-        }
         bool solid = false;
         if (near_cyl) solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);   // block-uniform branch
         T rho_bc, u_out;
@@ -861,107 +857,119 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
             for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
         }
     };
-    bool bad = false;
+    // The whole tile twice: LEAN = every cell of every level is a plain fluid cell (no boundary, ghost, solid or validity
+    // logic, buffer addressing); a block takes one of the two (block-uniform), so neither pays for merging with the other.
+    auto run = [&]<bool LEAN>() {
+        bool bad = false;
 #pragma unroll
-    for (int r = threadIdx.x; r < R1W * R1H; r += NTH) {                 // level 1 on region 1: iteration t
-        const int ry = r / R1W, rx = r - ry * R1W;
-        const int x = X0 + rx - HW, y = Y0 + ry - HW;
-        const int yg = a.y_start + y;
-        const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
-        T f[Q];
-        if (lean) {                                                       // block-uniform
-            const unsigned ub = (unsigned)(Y0 - HW + GR) * pitchB + (unsigned)(a.xoff + X0 - HW) * (unsigned)sizeof(T) + KB;
-            const unsigned voff = (unsigned)ry * pitchB + (unsigned)rx * (unsigned)sizeof(T);
-#pragma unroll
-            for (int i = 0; i < Q; ++i)
-                f[i] = buf_load<T>(rsrc, voff, ub + (unsigned)i * planeB - (unsigned)cy(i) * pitchB - (unsigned)(cx(i) * (int)sizeof(T)));
-            update(f, x, yg, true, bad);
-        } else if (!(row_in && col_in) || y > y_end + HW - 1) {
-#pragma unroll
-            for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
-        } else {
-            const long c = (long)(y + GR) * a.pitch + a.xoff + x;
-#pragma unroll
-            for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
-            update(f, x, yg, true, bad);
-        }
-#pragma unroll
-        for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
-    }
-    if (bad) atomicMin(a.unstable_t, a.t);
-    __syncthreads();
-    auto in_place = [&]<int L>() {                                        // level L on region L = region 1 shrunk by L-1 rings
-        constexpr int O = L - 1, RW = R1W - 2 * O, RH = R1H - 2 * O, CPT = (RW * RH + NTH - 1) / NTH;
-        T g[CPT][Q];
-        int cell[CPT];
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            const int r = (int)threadIdx.x + k * NTH;
-            cell[k] = (r < RW * RH) ? r : -1;
-            if (cell[k] >= 0) {
-                const int ry = r / RW + O, rx = r - (r / RW) * RW + O;
-#pragma unroll
-                for (int i = 0; i < Q; ++i) g[k][i] = lds[i][ry - cy(i)][rx - cx(i)];
-            }
-        }
-        __syncthreads();
-        bool badl = false;
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            if (cell[k] < 0) continue;
-            const int r = cell[k];
-            const int ry = r / RW + O, rx = r - (r / RW) * RW + O;
-            const int x = X0 + rx - HW, y = Y0 + ry - HW;
-            const int yg = a.y_start + y;
-            const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+        for (int r = threadIdx.x; r < R1W * R1H; r += NTH) {                 // level 1 on region 1: iteration t
+            const int ry = r / R1W, rx = r - ry * R1W;
             T f[Q];
-            if (!lean && !(row_in && col_in)) {
+            if (LEAN) {
+                const unsigned ub = (unsigned)(Y0 - HW + GR) * pitchB + (unsigned)(a.xoff + X0 - HW) * (unsigned)sizeof(T) + KB;
+                const unsigned voff = (unsigned)ry * pitchB + (unsigned)rx * (unsigned)sizeof(T);
 #pragma unroll
-                for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
+                for (int i = 0; i < Q; ++i)
+                    f[i] = buf_load<T>(rsrc, voff, ub + (unsigned)i * planeB - (unsigned)cy(i) * pitchB - (unsigned)(cx(i) * (int)sizeof(T)));
+                bad |= any_unstable(f);
+                bgk_collide<T, AR>(f, a.tau_inv);
             } else {
+                const int x = X0 + rx - HW, y = Y0 + ry - HW;
+                const int yg = a.y_start + y;
+                const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+                if (!(row_in && col_in) || y > y_end + HW - 1) {
 #pragma unroll
-                for (int i = 0; i < Q; ++i) f[i] = g[k][i];
-                update(f, x, yg, y <= y_end + HW - L, badl);
+                    for (int i = 0; i < Q; ++i) f[i] = outside_value(row_in, col_in, i);
+                } else {
+                    const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+#pragma unroll
+                    for (int i = 0; i < Q; ++i) f[i] = a.src[(long)i * a.plane + c - (long)cy(i) * a.pitch - cx(i)];
+                    update(f, x, yg, true, bad);
+                }
             }
 #pragma unroll
             for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
         }
-        if (badl) atomicMin(a.unstable_t, a.t + L - 1);
+        if (bad) atomicMin(a.unstable_t, a.t);
         __syncthreads();
-    };
-    [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (in_place.template operator()<Ls + 2>(), ...); }(std::make_integer_sequence<int, D - 2>{});
-    bad = false;
-    {                                                                     // level D on the tile: iteration t+D-1
-        const int o = threadIdx.x;
-        const int ly = o / TX, lx = o - ly * TX;
-        const int x = X0 + lx, y = Y0 + ly;
-        if (y < y_end && x < a.nx) {
-            const int yg = a.y_start + y;
-            T f[Q];
+        auto in_place = [&]<int L>() {                                        // level L on region L = region 1 shrunk by L-1 rings
+            constexpr int O = L - 1, RW = R1W - 2 * O, RH = R1H - 2 * O, CPT = (RW * RH + NTH - 1) / NTH;
+            T g[CPT][Q];
+            int cell[CPT];
 #pragma unroll
-            for (int i = 0; i < Q; ++i) f[i] = lds[i][ly + HW - cy(i)][lx + HW - cx(i)];
-            const bool solid = !lean && near_cyl && is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
-            T rho_bc, u_out;
-            if (!lean && !solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
-            bad |= any_unstable(f);
-            if (lean) {                                                   // block-uniform
-                bgk_collide<T, AR>(f, a.tau_inv);
-                const unsigned ub = (unsigned)(Y0 + GR) * pitchB + (unsigned)(a.xoff + X0) * (unsigned)sizeof(T);
-                const unsigned voff = (unsigned)ly * pitchB + (unsigned)lx * (unsigned)sizeof(T);
+            for (int k = 0; k < CPT; ++k) {
+                const int r = (int)threadIdx.x + k * NTH;
+                cell[k] = (r < RW * RH) ? r : -1;
+                if (cell[k] >= 0) {
+                    const int ry = r / RW + O, rx = r - (r / RW) * RW + O;
 #pragma unroll
-                for (int i = 0; i < Q; ++i) buf_store<NT>(f[i], rdst, voff, ub + (unsigned)i * planeB);
-            } else if (!solid) {
-                bgk_collide<T, AR>(f, a.tau_inv);
-                const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+                    for (int i = 0; i < Q; ++i) g[k][i] = lds[i][ry - cy(i)][rx - cx(i)];
+                }
+            }
+            __syncthreads();
+            bool badl = false;
 #pragma unroll
-                for (int i = 0; i < Q; ++i) {
-                    T* p = a.dst + (long)i * a.plane + c;
-                    if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
+            for (int k = 0; k < CPT; ++k) {
+                if (cell[k] < 0) continue;
+                const int r = cell[k];
+                const int ry = r / RW + O, rx = r - (r / RW) * RW + O;
+                if (LEAN) {
+                    badl |= any_unstable(g[k]);
+                    bgk_collide<T, AR>(g[k], a.tau_inv);
+                } else {
+                    const int x = X0 + rx - HW, y = Y0 + ry - HW;
+                    const int yg = a.y_start + y;
+                    const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
+                    if (!(row_in && col_in)) {
+#pragma unroll
+                        for (int i = 0; i < Q; ++i) g[k][i] = outside_value(row_in, col_in, i);
+                    } else update(g[k], x, yg, y <= y_end + HW - L, badl);
+                }
+#pragma unroll
+                for (int i = 0; i < Q; ++i) lds[i][ry][rx] = g[k][i];
+            }
+            if (badl) atomicMin(a.unstable_t, a.t + L - 1);
+            __syncthreads();
+        };
+        [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (in_place.template operator()<Ls + 2>(), ...); }(std::make_integer_sequence<int, D - 2>{});
+        bad = false;
+        {                                                                     // level D on the tile: iteration t+D-1
+            const int o = threadIdx.x;
+            const int ly = o / TX, lx = o - ly * TX;
+            const int x = X0 + lx, y = Y0 + ly;
+            if (LEAN || (y < y_end && x < a.nx)) {
+                const int yg = a.y_start + y;
+                T f[Q];
+#pragma unroll
+                for (int i = 0; i < Q; ++i) f[i] = lds[i][ly + HW - cy(i)][lx + HW - cx(i)];
+                if (LEAN) {
+                    bad |= any_unstable(f);
+                    bgk_collide<T, AR>(f, a.tau_inv);
+                    const unsigned ub = (unsigned)(Y0 + GR) * pitchB + (unsigned)(a.xoff + X0) * (unsigned)sizeof(T);
+                    const unsigned voff = (unsigned)ly * pitchB + (unsigned)lx * (unsigned)sizeof(T);
+#pragma unroll
+                    for (int i = 0; i < Q; ++i) buf_store<NT>(f[i], rdst, voff, ub + (unsigned)i * planeB);
+                } else {
+                    const bool solid = near_cyl && is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
+                    T rho_bc, u_out;
+                    if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
+                    bad |= any_unstable(f);
+                    if (!solid) {
+                        bgk_collide<T, AR>(f, a.tau_inv);
+                        const long c = (long)(y + GR) * a.pitch + a.xoff + x;
+#pragma unroll
+                        for (int i = 0; i < Q; ++i) {
+                            T* p = a.dst + (long)i * a.plane + c;
+                            if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
+                        }
+                    }
                 }
             }
         }
-    }
-    if (bad) atomicMin(a.unstable_t, a.t + D - 1);
+        if (bad) atomicMin(a.unstable_t, a.t + D - 1);
+    };
+    if (lean) run.template operator()<true>();
+    else run.template operator()<false>();
 }
 
 // D iterations per launch with a SLIDING WINDOW in y (temporal blocking without y-overlap). A block owns a column of
