@@ -252,7 +252,8 @@ void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream
 #undef LBM_KS
         return;
     }
-    if (c->deep_now && depth == deep_depth(c->deep)) {    // D iterations on a deep tile (k_stepd_tile; whole-domain launches)
+    if (c->deep_now) {    // D iterations on a deep tile (k_stepd_tile; whole-domain launches)
+        const int shape = c->deep >= 4 ? (depth == 5 ? 4 : 5) : c->deep;   // (the 32x16 family: kernel by depth)
         const bool fastd = c->arith == AR_CONTRACTED;
 #define LBM_KD(TX_, TY_, D_) do { \
         dim3 gridd((c->nx + TX_ - 1) / TX_, (a.y_cnt + TY_ - 1) / TY_ + (a.y_cnt2 + TY_ - 1) / TY_); \
@@ -260,7 +261,7 @@ void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream
                          else hipLaunchKernelGGL((k_stepd_tile<T, TX_, TY_, D_, true, true, AR_STRICT>), gridd, dim3(TX_ * TY_), 0, s, a, e); } \
         else { if (fastd) hipLaunchKernelGGL((k_stepd_tile<T, TX_, TY_, D_, false, true, AR_CONTRACTED>), gridd, dim3(TX_ * TY_), 0, s, a, e); \
                else hipLaunchKernelGGL((k_stepd_tile<T, TX_, TY_, D_, false, true, AR_STRICT>), gridd, dim3(TX_ * TY_), 0, s, a, e); } } while (0)
-        switch (c->deep) {
+        switch (shape) {
             case 1: LBM_KD(64, 16, 6); break;
             case 2: LBM_KD(64, 16, 7); break;
             case 3: LBM_KD(32, 32, 8); break;
@@ -524,32 +525,34 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
         // a deep plan: D iterations while D fit, then the four-/three-/two-iteration tile kernels for what is left
         const int deep = (!any_face && !c->slide && c->deep) ? deep_depth(c->deep) : 0;
         if (deep) {
-            bool ok = room >= deep;
-            for (int j = 1; j < deep; ++j) ok = ok && !(of > 0 && (t + j) % of == 0);
-            dmax = std::min(4, deep - 1);
-            if (ok && of <= 0 && room < 3 * deep && room % deep != 0) {
-                // The tail of a call whose length is no multiple of the depth: 20 = 6 + 6 + 4 + 4 costs less than
-                // 6 + 6 + 6 + 2 (the two- and one-iteration kernels run at half and a third of the fused rate). Cheapest
-                // split of `room` into launches of depth D, 4, 3, 2, 1 (relative cost per iteration from the measurements).
-                static const double per_it[5] = {2.8, 1.6, 1.12, 1.08, 1.0};     // depth 1, 2, 3, 4, D
+            // `seg` iterations may be fused from here: up to the next force-output iteration (its post-collision state
+            // must exist in memory) and the end of the call. A long segment takes the plan's depth; near its end the
+            // cheapest split into launches of the available depths is taken instead (20 = 5 + 5 + 5 + 5 or 6 + 6 + 4 + 4
+            // rather than 6 + 6 + 6 + 2: the two- and one-iteration kernels run at half and a third of the fused rate).
+            // The 32x16 shapes exist with five and with six iterations per launch and the plan may use both.
+            const int seg = of > 0 ? std::min(room, of - t % of) : room;
+            const int alt = c->deep == 4 ? 6 : c->deep == 5 ? 5 : 0;
+            dmax = std::min(4, std::min(deep, alt ? alt : deep) - 1);
+            if (seg >= 4 * deep) depth = deep;
+            else if (seg >= 2) {
+                static const double per_it[4] = {2.8, 1.6, 1.12, 1.08};          // depth 1..4 relative to the deep kernel
                 double best[64];
                 int first[64];
                 best[0] = 0.0; first[0] = 0;
-                for (int r = 1; r <= room; ++r) {
+                for (int r = 1; r <= seg; ++r) {
                     best[r] = 1e30; first[r] = 1;
-                    const int opts[5] = {1, 2, 3, 4, deep};
-                    for (int k = 0; k < 5; ++k) {
-                        const int d = opts[k];
-                        if (d > r || (k < 4 && d > dmax)) continue;
-                        const double cst = best[r - d] + per_it[k] * d;
-                        if (cst < best[r] - 1e-12) { best[r] = cst; first[r] = d; }
+                    for (int d = 1; d <= std::min(r, 8); ++d) {
+                        const bool is_deep = (d == deep || d == alt);
+                        if (!is_deep && d > dmax) continue;
+                        const double cst = best[r - d] + (is_deep ? 1.0 : per_it[d - 1]) * d;
+                        if (cst < best[r] - 1e-12 || (is_deep && d == deep && cst < best[r] + 1e-12)) { best[r] = cst; first[r] = d; }
                     }
                 }
-                if (first[room] == deep) depth = deep;
-                else { ok = false; dmax = first[room]; }
-            } else if (ok) depth = deep;
+                depth = first[seg];
+            }
+            c->deep_now = depth > 1 && (depth == deep || depth == alt);
+            dmax = depth;       // (decided: the generic rule below only confirms it)
         }
-        c->deep_now = depth > 1 && depth == deep;
         // A three-iteration plan leaves a one- or two-iteration launch at the end of a call whose length is not a
         // multiple of three, which runs at half the rate. Where the four-iteration kernel is usable, one (remainder 1)
         // or two (remainder 2) four-iteration launches absorb it: 20 = 4 + 4 + 3 + 3 + 3 + 3.
