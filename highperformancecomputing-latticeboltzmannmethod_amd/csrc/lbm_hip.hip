@@ -214,6 +214,7 @@ inline int deep_depth(int id) {
     static const int d[6] = {0, 6, 7, 8, 5, 6};
     return id >= 0 && id <= 5 ? d[id] : 0;
 }
+inline int deep_rows(int id) { return id == 3 ? 32 : 16; }     // tile height
 inline const char* deep_tile(int id) {
     static const char* t[6] = {"", "64,16", "64,16", "32,32", "32,16", "32,16"};
     return id >= 0 && id <= 5 ? t[id] : "";
@@ -518,12 +519,15 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
     const int t = c->steps_done;
     int depth = 1;
     const bool any_face = strip_logic && (face_south(c) || face_north(c));
+    bool deep_plan = false;      // a deep plan exchanges after every launch (no extended first launch of a pair)
     c->deep_now = false;
     if (c->fuse > 1) {
         const int room = remaining - (c->trailing_pair ? 0 : 1);       // iterations a fused launch may take now
         int dmax = std::min(c->fuse, (any_face || c->slide) ? 3 : 4);  // (four: k_step4_tile, no faces)
         // a deep plan: D iterations while D fit, then the four-/three-/two-iteration tile kernels for what is left
-        const int deep = (!any_face && !c->slide && c->deep) ? deep_depth(c->deep) : 0;
+        // (a strip with faces: its ghost rows go GR deep and are refreshed after every launch, so a deep launch of up to GR
+        // iterations works there too — the 32x16 and 64x16 shapes with five / six iterations, not the seven / eight ones)
+        const int deep = (!c->slide && c->deep && (!any_face || deep_depth(c->deep) <= GR)) ? deep_depth(c->deep) : 0;
         if (deep) {
             // `seg` iterations may be fused from here: up to the next force-output iteration (its post-collision state
             // must exist in memory) and the end of the call. A long segment takes the plan's depth; near its end the
@@ -532,7 +536,7 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
             // The 32x16 shapes exist with five and with six iterations per launch and the plan may use both.
             const int seg = of > 0 ? std::min(room, of - t % of) : room;
             const int alt = c->deep == 4 ? 6 : c->deep == 5 ? 5 : 0;
-            dmax = std::min(4, std::min(deep, alt ? alt : deep) - 1);
+            dmax = std::min(any_face ? 3 : 4, std::min(deep, alt ? alt : deep) - 1);
             if (seg >= 4 * deep) depth = deep;
             else if (seg >= 2) {
                 static const double per_it[4] = {2.8, 1.6, 1.12, 1.08};          // depth 1..4 relative to the deep kernel
@@ -552,6 +556,7 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
             }
             c->deep_now = depth > 1 && (depth == deep || depth == alt);
             dmax = depth;       // (decided: the generic rule below only confirms it)
+            deep_plan = true;
         }
         // A three-iteration plan leaves a one- or two-iteration launch at the end of a call whose length is not a
         // multiple of three, which runs at half the rate. Where the four-iteration kernel is usable, one (remainder 1)
@@ -568,7 +573,7 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
     const bool faces = strip_logic && (face_south(c) || face_north(c));
     const bool last = remaining - depth <= 0;
     L->depth = depth; L->src = c->cur; L->dst = c->cur ^ 1; L->t = t;
-    if (faces && c->deep_halo && !last && !c->mid_pair) L->kind = KIND_EXTENDED;
+    if (faces && c->deep_halo && !last && !c->mid_pair && !deep_plan) L->kind = KIND_EXTENDED;
     else {
         if (faces && !transport && !last)
             return fail(LBM_ERR_ARG, "a strip with host-staged halos can take at most two launches per lbm_step call "
@@ -589,7 +594,7 @@ int issue_before(lbm_ctx* c, const Launch& L) {
         HIPCHK(hipGetLastError());
         return LBM_OK;
     }
-    const int E = L.depth > 1 ? (c->slide ? GR : c->pair_ty) : GR;   // one tile band / one band of the sliding kernel
+    const int E = c->deep_now ? deep_rows(c->deep) : L.depth > 1 ? (c->slide ? GR : c->pair_ty) : GR;   // one tile band / one band of the sliding kernel
     if (L.kind == KIND_EXTENDED) {   // all rows of the strip PLUS the EXT ghost rows next to each internal face
         const int es = face_south(c) ? EXT : 0, en = face_north(c) ? EXT : 0;
         int e0 = face_south(c) ? E : 0, e1 = face_north(c) ? E : 0;
@@ -810,15 +815,25 @@ int choose_plan(lbm_ctx* c) {
     const size_t need = 2 * buffer_bytes(c);
     // tiny grids are launch/latency bound (nothing to choose); huge ones cannot afford a second live allocation
     const bool can_tune = c->tune && (size_t)c->nx * c->nyl >= (1u << 16) && 2 * need + (1u << 28) < free_b;
+    // the strip rule (see below): a function of the global grid and the number of strips only, so that every rank —
+    // measuring or not — issues the same launch depths
+    const int nstrips = c->group_n > 1 ? c->group_n : (c->comm && c->nranks > 1) ? c->nranks : 1;
+    const bool strip_deep = strips && c->p.ny / nstrips >= 64;
     if (!c->tune) cand.push_back(fixed);
     else if (!can_tune) {
-        if (strips) cand.push_back({1, 1, 1, 0, p2 ? 3 : 1, 12, 1, "row-interleaved (default, not measured)"});
+        if (strip_deep) cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 32x16 (default, not measured)", 0, 5});
+        else if (strips) cand.push_back({1, 1, 1, 0, p2 ? 3 : 1, 12, 1, "row-interleaved (default, not measured)"});
         else cand.push_back({0, vec_ok ? 0 : 1, 1, 0, p2 ? 3 : 1, 12, 0, "planar (default, not measured)"});
     } else {
         // Strips exchange GR rows x 9 sub-rows as one contiguous run: row-interleaved only. Every rank must issue the
         // same sequence of launches (one exchange per launch), so the fusion depth and tile height of a strip run are
-        // fixed by rule (3 iterations, 64x12 tiles); only rank-local choices are measured.
-        if (strips) {
+        // fixed by rule — a function of the global grid and the number of strips only: 6 iterations on 32x16 tiles where
+        // a strip has 64 rows or more, else 3 iterations on 64x12 tiles; only rank-local choices are measured.
+        if (strip_deep) {
+            // tall strips: six (five) iterations per launch on 32x16 tiles, one exchange of the GR rows after every launch
+            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 32x16/nt-store/xcd", 0, 5});
+            cand.push_back({1, 1, 0, 0, 6, 12, 1, "row-interleaved/6-step 32x16/xcd", 0, 5});
+        } else if (strips) {
             const int f = p2 ? 3 : 1;
             if (p2) cand.push_back({1, 1, 1, 0, f, 12, 1, "row-interleaved/3-step sliding 64-column/nt-store", 1});
             if (p2) cand.push_back({1, 1, 0, 0, f, 12, 1, "row-interleaved/3-step sliding 64-column", 1});

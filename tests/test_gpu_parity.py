@@ -80,8 +80,13 @@ def fused_depth(plan_opts, steps_left, done, of):
     """The depth the library picks for the next launch (lbm_hip.hip: advance) when it is asked for exactly that many
     iterations with trailing_pair=1 — the host-staged strip drivers below must issue ONE launch per lbm_step call."""
     maxd = (plan_opts or {}).get("fuse", 2 if (plan_opts or {}).get("pair") else 1)
-    if (plan_opts or {}).get("deep"):
-        maxd = 3                                     # a strip has faces: the deep kernel is not used there
+    deep = (plan_opts or {}).get("deep", 0)
+    if deep:
+        maxd = 3                                     # what is left of a segment goes to the three-/two-iteration kernels
+        depths = {1: (6,), 4: (6, 5), 5: (6, 5)}.get(deep, ())      # a strip's ghost rows go six deep: no 7 / 8
+        for d in depths:
+            if steps_left >= d + 1 and all(of <= 0 or (done + j) % of != 0 for j in range(1, d)):
+                return d
     for d in (3, 2):
         if d <= maxd and steps_left >= d + 1 and all(of <= 0 or (done + j) % of != 0 for j in range(1, d)):
             return d
@@ -360,7 +365,8 @@ def test_overlap_choreography_with_loopback_halo(lbm, pair):
 
 
 @pytest.mark.parametrize("overlap,deep", [(1, 1), (0, 1), (1, 0), (0, 0), (2, 1), (2, 0)])
-@pytest.mark.parametrize("plan", ["rowil-fuse3-12-nt-xcd", "rowil-slide3", "rowil-site-nt", "fast-rowil-slide2"])
+@pytest.mark.parametrize("plan", ["rowil-fuse3-12-nt-xcd", "rowil-slide3", "rowil-site-nt", "fast-rowil-slide2",
+                                  "rowil-half5-nt", "fast-rowil-half5", "rowil-deep6-nt"])
 def test_group_of_strips_on_one_device_matches_single_domain_bitwise(lbm, plan, overlap, deep):
     """In-process strips (lbm_group_*, the transport `lbm_solver --gpus N` uses) with the production choreography: edge
     bands on the side stream, every strip PULLING its neighbours' edge rows with exactly the pointers / offsets / counts
@@ -393,6 +399,29 @@ def test_group_of_strips_on_one_device_matches_single_domain_bitwise(lbm, plan, 
         assert g.max_velocity_sq() == w[5]
         with pytest.raises(lbm.LbmError, match="member of a group"):
             g.ctxs[0].step(1, 0)
+
+
+def test_tall_strips_take_the_deep_plan_by_rule(lbm):
+    """A measured (tune=1) group whose strips have 64 rows or more runs six iterations per launch on 32x16 tiles with one
+    exchange per launch — chosen by rule from the global grid and the strip count, so that every strip (every rank of a
+    multi-process run) issues the same launch depths — and reproduces the one-domain run bit for bit."""
+    nx, ny, steps, of = 512, 200, 333, 70
+    kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
+    with lbm.Context(nx, ny, options=PLANS["rowil-site-nt"], **kw) as whole:
+        whole.initialise()
+        whole.step(steps, of)
+        w_fn, w_log = whole.populations("f_next"), whole.drain_force_log()
+    for extra in (dict(), dict(overlap=0), dict(group_threads=0)):
+        with lbm.Group(nx, ny, 3, options=extra or None, **kw) as g:
+            g.initialise()
+            assert all("6-step 32x16" in m.plan() for m in g.ctxs), [m.plan() for m in g.ctxs]
+            g.step(steps, of)
+            assert g.first_unstable_step() == -1
+            assert np.array_equal(g.populations("f_next"), w_fn)
+            log = g.drain_force_log()
+            assert [r[0] for r in log] == [r[0] for r in w_log]
+            for (t, fx, fy), (_, wx, wy) in zip(log, w_log):
+                assert abs(fx - wx) <= 1e-13 * max(1.0, abs(wx)) and abs(fy - wy) <= 1e-13
 
 
 def test_group_checkpoint_restart(lbm, tmp_path):
