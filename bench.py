@@ -136,6 +136,7 @@ def main():
                     help="strong: the named grid cut into N strips (BASELINE metric); weak: ny rows PER GPU")
     ap.add_argument("--set", action="append", default=[], help="library option key=value (lbm_set_option), e.g. slide=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-arith", action="store_true", help="skip the run in the other arithmetic mode (profiler passes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -222,7 +223,7 @@ def main():
         ctx.set_option("skip_exchange", 0)
 
     other = None
-    if world == 1:
+    if world == 1 and not args.no_other_arith:
         # the same workload in the OTHER arithmetic mode, same harness, reported beside the headline (not part of `value`)
         oa = "strict" if args.arith == "contracted" else "contracted"
         with lbm.Context(nx, ny_total, tau=0.6, inlet_velocity=u_in, precision=args.precision, device=device,
@@ -248,8 +249,8 @@ def main():
         kernel = ctx.kernel_name()
         traffic, tnote = measured_traffic(nx, local_ny, args.precision, kernel, ctx.plan().split("/")[0])
         equiv = launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        m = re.match(r"k_step(\d)_tile|k_step_slide<\w+,(\d)", kernel)
-        plan_depth = int(m.group(1) or m.group(2)) if m else 1
+        m = re.match(r"k_step(\d)_tile|k_step_slide<\w+,(\d)|k_stepd_tile<\w+,\d+,\d+,(\d)", kernel)
+        plan_depth = int(m.group(1) or m.group(2) or m.group(3)) if m else 1
         if traffic and abs(ipl - plan_depth) > 0.01 * plan_depth:
             # a short call mixes launch depths (e.g. 20 = 4+4+3+3+3+3, or a two-iteration tail): the PMC figure belongs to the
             # plan's kernel at its own depth; scale it to the mean depth of the timed launches
@@ -282,6 +283,10 @@ def main():
                          "kernel": kernel, "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": launch_bytes, "iterations_per_launch": round(ipl, 4),
                          "equiv_144B_gbs": round(equiv, 1), "equiv_144B_frac": round(equiv / HBM_PEAK_GBS, 4),
+                         "limiter": "not HBM: a launch fuses several iterations through LDS precisely to move fewer bytes per update "
+                                    "(DESIGN.md §3: VALU ~53 % busy, LDS ~34 %, HBM ~0.5 of peak on the six-iteration kernel; the "
+                                    "barrier-separated LDS/VALU phases of a block bound it)" if plan_depth >= 4 else
+                                    "HBM first (the kernel moves 0.6-0.8 of the peak), then the exposed latency of its load phase",
                          "note": "frac = HBM bytes actually moved per launch / time / peak (<= 1). equiv_144B_* price every lattice update at "
                                  "the unfused 144 B (72 B fp32): a launch that fuses d iterations through LDS moves ~1/d of that, so the "
                                  "equivalent figure can exceed the peak; it is the number to compare with an unfused kernel's roofline"},

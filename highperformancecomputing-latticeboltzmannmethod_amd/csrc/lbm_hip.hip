@@ -527,7 +527,10 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
         // a deep plan: D iterations while D fit, then the four-/three-/two-iteration tile kernels for what is left
         // (a strip with faces: its ghost rows go GR deep and are refreshed after every launch, so a deep launch of up to GR
         // iterations works there too — the 32x16 and 64x16 shapes with five / six iterations, not the seven / eight ones)
-        const int deep = (!c->slide && c->deep && (!any_face || deep_depth(c->deep) <= GR)) ? deep_depth(c->deep) : 0;
+        // Whether the faces are EXCHANGED in this call (strip_logic) or not (the plan probe), a context whose rows end at an
+        // internal face has GR rows beyond them and no more: the seven- / eight-iteration shapes would read past the frame.
+        const bool phys_face = face_south(c) || face_north(c);
+        const int deep = (!c->slide && c->deep && (!phys_face || deep_depth(c->deep) <= GR)) ? deep_depth(c->deep) : 0;
         if (deep) {
             // `seg` iterations may be fused from here: up to the next force-output iteration (its post-collision state
             // must exist in memory) and the end of the call. A long segment takes the plan's depth; near its end the
@@ -573,7 +576,9 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
     const bool faces = strip_logic && (face_south(c) || face_north(c));
     const bool last = remaining - depth <= 0;
     L->depth = depth; L->src = c->cur; L->dst = c->cur ^ 1; L->t = t;
-    if (faces && c->deep_halo && !last && !c->mid_pair && !deep_plan) L->kind = KIND_EXTENDED;
+    // (an extended launch recomputes EXT ghost rows and leaves GR - EXT valid ones: launches of up to EXT iterations only;
+    // a deep plan with a device transport exchanges after every launch instead)
+    if (faces && c->deep_halo && !last && !c->mid_pair && depth <= EXT && !(deep_plan && transport)) L->kind = KIND_EXTENDED;
     else {
         if (faces && !transport && !last)
             return fail(LBM_ERR_ARG, "a strip with host-staged halos can take at most two launches per lbm_step call "
@@ -845,7 +850,7 @@ int choose_plan(lbm_ctx* c) {
             cand.push_back({1, 1, 1, 0, 5, 12, 1, "row-interleaved/5-step 32x16/nt-store/xcd", 0, 4});   // two 512-thread blocks per CU (fp64)
             cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 32x16/nt-store/xcd", 0, 5});
             cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x16/nt-store/xcd", 0, 1});
-            if (small_grid) {   // one round of LDS-filling tiles: a launch's load and store phases are paid once per 7-8 iterations
+            if (small_grid && !face_south(c) && !face_north(c)) {   // one round of LDS-filling tiles: a launch's load and store phases are paid once per 7-8 iterations
                 cand.push_back({1, 1, 1, 0, 7, 12, 1, "row-interleaved/7-step 64x16/nt-store/xcd", 0, 2});
                 cand.push_back({1, 1, 1, 0, 8, 12, 1, "row-interleaved/8-step 32x32/nt-store/xcd", 0, 3});
             }

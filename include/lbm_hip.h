@@ -67,13 +67,14 @@ void lbm_destroy(lbm_ctx* c);
 int  lbm_initialise(lbm_ctx* c, int* solid_count_out);
 
 /* `nsteps` loop bodies of Solver::run (LBMSolver.h:49-60): exchange + stream + BCs + stability of iteration
- * t, fused with collision_step() of iteration t+1; up to three (four for a context without strip faces) consecutive
- * iterations share one kernel launch
+ * t, fused with collision_step() of iteration t+1; up to six (eight on grids of a single round of blocks) consecutive
+ * iterations share one kernel launch, as many as the measured plan fuses
  * (intermediate states stay in LDS; results are bit-identical to one launch per iteration). Asynchronous on the
  * context's streams. If output_frequency > 0, record_forces is evaluated on-device for every
  * t % output_frequency == 0 inside the range (LBMSolver.h:52-54) and appended to the force log. The last iteration
  * of a call is always a launch of its own, so that the snapshots below refer to iteration steps_done-1. With a
- * communicator attached (lbm_comm_init) the strip's edge rows are exchanged once per two launches (replaces
+ * communicator attached (lbm_comm_init) the strip's six edge rows per face are exchanged once per launch of five / six
+ * iterations (strips of 64 rows or more) or once per two launches of up to three (replaces
  * Grid::exchange_ghost_cells, LBMGrid.h:249-283). */
 int  lbm_step(lbm_ctx* c, int nsteps, int output_frequency);
 
@@ -141,13 +142,14 @@ int  lbm_device_memory(int device, unsigned long long* free_bytes, unsigned long
 const char* lbm_strip_schedule(const lbm_ctx* c);
 /* Host-staged path (the buffers the reference hands to MPI_Isend/Irecv, LBMGrid.h:255-276). Each face buffer is
  * [LBM_HALO_ROWS][9][nx] doubles: the LBM_HALO_ROWS (= 6) interior rows next to that face, bottom row first, all nine
- * populations (six rows: up to two launches of up to three fused iterations each may run between two exchanges, the
- * first one recomputing three of the neighbour's rows).
+ * populations (six rows: one launch of up to six fused iterations — or two launches of up to three, the first one
+ * recomputing three of the neighbour's rows — may run between two exchanges).
  * export: south_out = my bottom rows, north_out = my top rows; import: south_in -> my south ghost rows (= the south
  * neighbour's north_out), north_in -> my north ghost rows. NULL = that side is a physical wall. The caller exchanges
  * after lbm_initialise and after EVERY lbm_step call, and calls lbm_step so that it issues at most TWO launches
  * (e.g. nsteps <= 4 by default = a fused launch of three iterations + a single one, or nsteps = 6 with the option
- * "trailing_pair" 1; lbm_step refuses a call that would need a third launch). Used by
+ * "trailing_pair" 1; with a "deep" plan ONE launch of up to six iterations; lbm_step refuses a call that would need
+ * more). Used by
  * MPI-hosted callers and by the 2-rank tests. */
 #define LBM_HALO_ROWS 6
 int  lbm_halo_export(lbm_ctx* c, double* south_out, double* north_out);
@@ -168,6 +170,11 @@ int  lbm_load_state(lbm_ctx* c, const char* path);
  *                 "pair" 1 == "fuse" 2), "pair_ty" 8|12 tile height, "xcd" XCD-aware tile walk,
  *                 "trailing_pair" 1 lets an lbm_step call end on a fused launch (snapshots then need one more step)
  *                 "slide" 1 the sliding-window fused kernel (k_step_slide) instead of the 2-D tile kernels,
+ *                 "deep" 1..5 the deep tile kernel (k_stepd_tile): 1 six iterations per launch on 64x16 tiles, 2 seven on
+ *                 64x16, 3 eight on 32x32 (1024-thread blocks: grids of a single round of blocks), 4 / 5 five / six
+ *                 iterations on 32x16 tiles (512-thread blocks, two per CU in fp64: large grids; a plan of this family
+ *                 uses both depths to split a call without a slow tail). Strips use 1, 4, 5 (a ghost frame is six rows
+ *                 deep) with one exchange per launch,
  *                 "arith" 0 strict IEEE collision (bit-identical to the CPU oracle) | 1 FMA-contracted (<= 1e-10)
  *   strips:       "overlap" 0 launch and exchange serialised | 1 edge bands first, the exchange overlapped with the interior
  *                 rows of the SAME launch | 2 the exchange overlapped with the interior rows of the NEXT (extended)
@@ -180,7 +187,7 @@ int  lbm_set_option(lbm_ctx* c, const char* key, long value);
  * the last lbm_step call; 0 if events were not enabled via lbm_set_option(c, "timing", 1). */
 int  lbm_last_step_kernel_ms(lbm_ctx* c, double* ms_per_launch);
 /* Same measurement, unreduced: device milliseconds of the last lbm_step call, the step-kernel launches it issued and
- * the iterations it advanced (a fused launch advances two or three). */
+ * the iterations it advanced (a fused launch advances two to eight). */
 int  lbm_last_step_stats(lbm_ctx* c, double* ms_total, int* launches, int* iterations);
 const char* lbm_kernel_name(const lbm_ctx* c);
 /* The plan lbm_initialise settled on (layout / kernel / store policy / traversal), for logs. */

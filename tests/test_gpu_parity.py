@@ -401,6 +401,43 @@ def test_group_of_strips_on_one_device_matches_single_domain_bitwise(lbm, plan, 
             g.ctxs[0].step(1, 0)
 
 
+@pytest.mark.parametrize("plan", [None, "rowil-half5-nt", "rowil-deep6-nt", "rowil-deep8-nt"])
+def test_host_staged_strips_calling_patterns(lbm, plan):
+    """The MPI-hosted calling pattern of INTEGRATION.md §C: lbm_step(4) = a fused launch of three iterations + a single
+    one, then the caller exchanges the edge rows — on contexts that measured their own plan (None: large enough to time the
+    candidates, deep ones included) and on pinned deep plans (the eight-iteration shape must fall back: a strip's ghost
+    frame is six rows deep); also one launch of six per call with trailing_pair. All reproduce the one-domain run."""
+    nx, ny = 1024, 256
+    kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
+    with lbm.Context(nx, ny, options=PLANS["rowil-site-nt"], **kw) as whole:
+        whole.initialise()
+        whole.step(48, 0)
+        w_fn = whole.populations("f_next")
+    for per_call, extra in ((4, {}), (6, dict(trailing_pair=1))):
+        opts = dict(PLANS[plan] if plan else {}, **extra) or None
+        ctxs = [lbm.Context(nx, ny, y_start=y0, local_ny=128, options=opts, **kw) for y0 in (0, 128)]
+        try:
+            for c in ctxs:
+                c.initialise()
+
+            def exchange():
+                lo, hi = ctxs[0].halo_export(south=False, north=True), ctxs[1].halo_export(south=True, north=False)
+                ctxs[0].halo_import(south=None, north=hi[0])
+                ctxs[1].halo_import(south=lo[1], north=None)
+            exchange()
+            calls = [4] * 12 if per_call == 4 else [6] * 7 + [1] * 6     # (a snapshot needs a call that ends on a single iteration)
+            for n in calls:
+                for c in ctxs:
+                    c.step(n, 0)
+                exchange()
+            parts = [c.populations("f_next") for c in ctxs]
+        finally:
+            for c in ctxs:
+                c.close()
+        # (each strip's array carries its own ghost frame: compare the interior rows)
+        assert np.array_equal(parts[0][1:129], w_fn[1:129]) and np.array_equal(parts[1][1:129], w_fn[129:257])
+
+
 def test_tall_strips_take_the_deep_plan_by_rule(lbm):
     """A measured (tune=1) group whose strips have 64 rows or more runs six iterations per launch on 32x16 tiles with one
     exchange per launch — chosen by rule from the global grid and the strip count, so that every strip (every rank of a

@@ -16,7 +16,11 @@ for n in (1, 2, 4, 8):
     rows = ny // n
     line = [f"N={n} rows={rows}:"]
     base = dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, arith=1, trailing_pair=1)
+    deep = dict(tune=0, layout=1, variant=1, nt=1, pair_ty=12, xcd=1, arith=1, trailing_pair=1, deep=5)
     for name, opts in (("no-exchange", dict(base)),
+                       ("no-exchange deep", dict(deep)),
+                       ("rccl-self deep ovl", dict(deep, loopback=2, overlap=1)),
+                       ("rccl-self deep ser", dict(deep, loopback=2, overlap=0)),
                        ("rccl-self TUNED", dict(arith=1, trailing_pair=1, loopback=2)),
                        ("rccl-self ovl+deep", dict(base, loopback=2, overlap=1, deep_halo=1)),
                        ("rccl-self ser+deep", dict(base, loopback=2, overlap=0, deep_halo=1)),
