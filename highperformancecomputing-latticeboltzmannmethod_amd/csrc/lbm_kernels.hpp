@@ -822,8 +822,22 @@ template <typename T, int TX, int TY, int D, bool NT, bool XCD, int AR = AR_STRI
 __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())) k_stepd_tile(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int NTH = TX * TY, HW = D - 1, R1W = TX + 2 * HW, R1H = TY + 2 * HW, LP = R1W;
     static_assert(D >= 3 && (NTH == 1024 || NTH == 512 || NTH == 256), "one tile cell per thread at the last level");
+    static_assert((TX & (TX - 1)) == 0, "cell_xy splits an index with a mask");
     static_assert((size_t)Q * R1H * LP * sizeof(T) <= 160 * 1024, "level-1 region must fit the CU's LDS");
     __shared__ T lds[Q][R1H][LP];
+    // Cell r of the region at ring offset O (rows and columns [O, R1 - O) of the LDS image) -> its LDS coordinates. The TX
+    // columns above the tile come first, row by row: a half-wave then covers one aligned run of 32 cells (no LDS bank
+    // conflict, whole cache lines at level 1) instead of a region row that wraps somewhere inside it; the 2 x (HW - O) halo
+    // columns of every row follow.
+    auto cell_xy = [&]<int O>(int r, int& ry, int& rx) {
+        constexpr int RH = R1H - 2 * O, HALO = HW - O, NC = RH * TX;
+        if (HALO == 0 || r < NC) { ry = O + r / TX; rx = HW + (r & (TX - 1)); }
+        else {
+            const int h = r - NC, q = h / (2 * HALO), c = h - q * (2 * HALO);
+            ry = O + q;
+            rx = c < HALO ? O + c : HW + TX + (c - HALO);
+        }
+    };
     int bx = blockIdx.x, by = blockIdx.y;
     if (XCD) {
         const int nb = gridDim.x * gridDim.y;
@@ -863,7 +877,8 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
         bool bad = false;
 #pragma unroll
         for (int r = threadIdx.x; r < R1W * R1H; r += NTH) {                 // level 1 on region 1: iteration t
-            const int ry = r / R1W, rx = r - ry * R1W;
+            int ry, rx;
+            cell_xy.template operator()<0>(r, ry, rx);
             T f[Q];
             if (LEAN) {
                 const unsigned ub = (unsigned)(Y0 - HW + GR) * pitchB + (unsigned)(a.xoff + X0 - HW) * (unsigned)sizeof(T) + KB;
@@ -901,7 +916,8 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
                 const int r = (int)threadIdx.x + k * NTH;
                 cell[k] = (r < RW * RH) ? r : -1;
                 if (cell[k] >= 0) {
-                    const int ry = r / RW + O, rx = r - (r / RW) * RW + O;
+                    int ry, rx;
+                    cell_xy.template operator()<O>(r, ry, rx);
 #pragma unroll
                     for (int i = 0; i < Q; ++i) g[k][i] = lds[i][ry - cy(i)][rx - cx(i)];
                 }
@@ -912,7 +928,8 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
             for (int k = 0; k < CPT; ++k) {
                 if (cell[k] < 0) continue;
                 const int r = cell[k];
-                const int ry = r / RW + O, rx = r - (r / RW) * RW + O;
+                int ry, rx;
+                cell_xy.template operator()<O>(r, ry, rx);
                 if (LEAN) {
                     badl |= any_unstable(g[k]);
                     bgk_collide<T, AR>(g[k], a.tau_inv);
