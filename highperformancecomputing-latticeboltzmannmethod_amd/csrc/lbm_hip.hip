@@ -781,8 +781,10 @@ int time_plan(lbm_ctx* c, float* ms_out) {
     if (rc) return rc;
     auto run = [&](int n) -> int {
         for (int k = 0; k < n;) {
-            const int took = advance<T>(c, n - k + 3, 0, false, false);   // +3: never end on the "last is single" rule;
-                                                                          // no strip logic: the probe times local launches
+            // far from the end of a call (and with a room that is a multiple of three, so that a three-iteration plan is not
+            // handed the four-iteration kernel for a remainder): every launch has the plan's own depth — a window is no
+            // multiple of 7 or 8. No strip logic: the probe times local launches.
+            const int took = advance<T>(c, 3 * (1 << 18) + (c->trailing_pair ? 0 : 1), 0, false, false);
             if (took < 0) return took;
             k += took;
         }
