@@ -512,6 +512,33 @@ def test_checkpoint_restart_is_bit_exact(lbm, tmp_path):
             c.load_state(tmp_path / "s.ckpt")
 
 
+@pytest.mark.parametrize("plan,steps,of,trailing,launches", [
+    ("rowil-half5-nt", 20, 0, 1, 4),        # 5+5+5+5
+    ("planar-half6", 22, 0, 1, 4),          # 6+6+5+5: the 32x16 family uses both of its depths
+    ("rowil-deep6-nt", 20, 0, 1, 4),        # 6+6+4+4 rather than 6+6+6+2
+    ("rowil-deep8-nt", 19, 0, 1, 3),        # 8+8+3
+    ("rowil-half5-nt", 20, 0, 0, 5),        # 5+5+5+4 and the single last iteration of a call that may be read back
+    ("rowil-half5-nt", 24, 10, 1, 5),       # force outputs at 10 and 20 end the fused segments: 5+5 | 5+5 | 4
+    ("rowil-fuse3-12-nt-xcd", 20, 0, 1, 6), # 4+4+3+3+3+3
+])
+def test_a_call_is_split_into_full_rate_launches(lbm, plan, steps, of, trailing, launches):
+    """plan_launch: the iterations of a call (between force outputs) are split into the cheapest sequence of the depths the
+    plan has — no one- or two-iteration tail where a different split avoids it — and the result is that of single launches."""
+    nx, ny = 256, 96
+    kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
+    with lbm.Context(nx, ny, options=PLANS["rowil-site-nt"], **kw) as one:
+        one.initialise()
+        one.step(steps + 1, of)
+        ref = one.populations("f_next")
+    with lbm.Context(nx, ny, options=dict(PLANS[plan], trailing_pair=trailing, timing=1), **kw) as ctx:
+        ctx.initialise()
+        ctx.step(steps, of)
+        _, n, its = ctx.last_step_stats()
+        assert (n, its) == (launches, steps)
+        ctx.step(1, of)                      # (a snapshot needs a call that ends on a single iteration)
+        assert np.array_equal(ctx.populations("f_next"), ref)
+
+
 def test_c4_grid_8192x2048_single_gpu(lbm):
     """BASELINE.json configs[3] grid (8192x2048, Re=200) on ONE GPU (the 8-GPU strip run belongs to the driver):
     bit-exact populations against the oracle over a bounded window, and decomposition invariance for 8 strips."""
