@@ -32,7 +32,8 @@ for n in (1, 2, 4, 8):
                 c.comm_init(0, 1, c.comm_unique_id())      # one-rank communicator: ncclSend/ncclRecv to self
             c.initialise()
             c.step(300, 0); c.sync()
-            t0 = time.perf_counter(); c.step(3000, 0); c.sync(); dt = time.perf_counter() - t0
+            t0 = time.perf_counter(); c.step(3000, 0); t1 = time.perf_counter(); c.sync(); dt = time.perf_counter() - t0
             extra = f" [{c.strip_schedule()} | {c.kernel_name()}]" if "TUNED" in name else ""
-            line.append(f"{name} {dt / 3000 * 1e6:.2f} us/it ({nx * rows * 3000 / dt / 1e6 * n:.0f} MLUPS x{n} ranks){extra}")
+            # (host: the time lbm_step needs to ISSUE the launches, events and exchanges — the floor of a host-bound strip)
+            line.append(f"{name} {dt / 3000 * 1e6:.2f} us/it, host {(t1 - t0) / 3000 * 1e6:.2f} ({nx * rows * 3000 / dt / 1e6 * n:.0f} MLUPS x{n} ranks){extra}")
     print("  ".join(line), flush=True)
