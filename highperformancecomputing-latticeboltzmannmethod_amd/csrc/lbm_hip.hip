@@ -1,6 +1,7 @@
 // csrc/lbm_hip.hip — host side of liblbm_hip.so: the C-ABI of include/lbm_hip.h over the gfx950 kernels in
 // lbm_kernels.hpp. Plain HIP runtime + RCCL; no torch types, no CPU fallback.
 #include "lbm_kernels.hpp"
+#include "lbm_kernel_col.hpp"
 #include "../../include/lbm_hip.h"
 
 #include <rccl/rccl.h>
@@ -209,12 +210,23 @@ void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
     }
 }
 
-// "deep" plans (k_stepd_tile): shape id -> iterations per launch and tile
+// "deep" plans: shape id -> iterations per launch and tile. 1..5: LDS-image tiles (k_stepd_tile); 6..8: the register-
+// resident column kernel (k_stepc_col, R = 4 rows per thread x 8 waves = a 64 x 32 region per block, two blocks per CU):
+// 6 / 7 = the five- / six-iteration members of that family (a plan of either uses both depths for what a segment leaves
+// over; seven and eight iterations were measured at 4096x1024 fp64 — 160.6 / 154.3 GLUPS against 161.7 — and are not built).
+constexpr int COL_R = 4, COL_NW = 8;
+inline bool deep_is_col(int id) { return id == 6 || id == 7; }
 inline int deep_depth(int id) {
-    static const int d[6] = {0, 6, 7, 8, 5, 6};
-    return id >= 0 && id <= 5 ? d[id] : 0;
+    static const int d[8] = {0, 6, 7, 8, 5, 6, 5, 6};
+    return id >= 0 && id <= 7 ? d[id] : 0;
 }
-inline int deep_rows(int id) { return id == 3 ? 32 : 16; }     // tile height
+// the other depth of a two-member family (32x16 tiles: ids 4/5, column kernel: ids 6/7), 0 if the shape stands alone
+inline int deep_alt_depth(int id) { return (id == 4 || id == 6) ? 6 : (id == 5 || id == 7) ? 5 : 0; }
+// rows of one band of tiles of a launch of `depth` iterations (the edge bands of a strip are one band each)
+inline int deep_rows(int id, int depth) {
+    if (deep_is_col(id)) return COL_R * COL_NW - 2 * (depth - 1);
+    return id == 3 ? 32 : 16;
+}
 inline const char* deep_tile(int id) {
     static const char* t[6] = {"", "64,16", "64,16", "32,32", "32,16", "32,16"};
     return id >= 0 && id <= 5 ? t[id] : "";
@@ -251,6 +263,20 @@ void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream
             default: LBM_KS(3, true, AR_CONTRACTED); break;
         }
 #undef LBM_KS
+        return;
+    }
+    if (c->deep_now && deep_is_col(c->deep)) {    // D iterations with the lattice in registers (k_stepc_col)
+        const bool fastd = c->arith == AR_CONTRACTED;
+#define LBM_KC(D_) do { \
+        constexpr int OW_ = 64 - 2 * (D_ - 1), OH_ = COL_R * COL_NW - 2 * (D_ - 1); \
+        const int nb_ = ((c->nx + OW_ - 1) / OW_) * ((a.y_cnt + OH_ - 1) / OH_ + (a.y_cnt2 + OH_ - 1) / OH_); \
+        const dim3 gridc((unsigned)round_up(nb_, 8)), blockc(COL_NW * 64); \
+        if (c->use_nt) { if (fastd) hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, true, AR_CONTRACTED>), gridc, blockc, 0, s, a, e); \
+                         else hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, true, AR_STRICT>), gridc, blockc, 0, s, a, e); } \
+        else { if (fastd) hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, false, AR_CONTRACTED>), gridc, blockc, 0, s, a, e); \
+               else hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, false, AR_STRICT>), gridc, blockc, 0, s, a, e); } } while (0)
+        if (depth == 5) LBM_KC(5); else LBM_KC(6);
+#undef LBM_KC
         return;
     }
     if (c->deep_now) {    // D iterations on a deep tile (k_stepd_tile; whole-domain launches)
@@ -538,7 +564,7 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
             // rather than 6 + 6 + 6 + 2: the two- and one-iteration kernels run at half and a third of the fused rate).
             // The 32x16 shapes exist with five and with six iterations per launch and the plan may use both.
             const int seg = of > 0 ? std::min(room, of - t % of) : room;
-            const int alt = c->deep == 4 ? 6 : c->deep == 5 ? 5 : 0;
+            const int alt = deep_alt_depth(c->deep);
             dmax = std::min(any_face ? 3 : 4, std::min(deep, alt ? alt : deep) - 1);
             if (seg >= 4 * deep) depth = deep;
             else if (seg >= 2) {
@@ -599,7 +625,7 @@ int issue_before(lbm_ctx* c, const Launch& L) {
         HIPCHK(hipGetLastError());
         return LBM_OK;
     }
-    const int E = c->deep_now ? deep_rows(c->deep) : L.depth > 1 ? (c->slide ? GR : c->pair_ty) : GR;   // one tile band / one band of the sliding kernel
+    const int E = c->deep_now ? deep_rows(c->deep, L.depth) : L.depth > 1 ? (c->slide ? GR : c->pair_ty) : GR;   // one tile band / one band of the sliding kernel
     if (L.kind == KIND_EXTENDED) {   // all rows of the strip PLUS the EXT ghost rows next to each internal face
         const int es = face_south(c) ? EXT : 0, en = face_north(c) ? EXT : 0;
         int e0 = face_south(c) ? E : 0, e1 = face_north(c) ? E : 0;
@@ -828,7 +854,7 @@ int choose_plan(lbm_ctx* c) {
     const bool strip_deep = strips && c->p.ny / nstrips >= 64;
     if (!c->tune) cand.push_back(fixed);
     else if (!can_tune) {
-        if (strip_deep) cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 32x16 (default, not measured)", 0, 5});
+        if (strip_deep) cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers (default, not measured)", 0, 7});
         else if (strips) cand.push_back({1, 1, 1, 0, p2 ? 3 : 1, 12, 1, "row-interleaved (default, not measured)"});
         else cand.push_back({0, vec_ok ? 0 : 1, 1, 0, p2 ? 3 : 1, 12, 0, "planar (default, not measured)"});
     } else {
@@ -837,9 +863,9 @@ int choose_plan(lbm_ctx* c) {
         // fixed by rule — a function of the global grid and the number of strips only: 6 iterations on 32x16 tiles where
         // a strip has 64 rows or more, else 3 iterations on 64x12 tiles; only rank-local choices are measured.
         if (strip_deep) {
-            // tall strips: six (five) iterations per launch on 32x16 tiles, one exchange of the GR rows after every launch
-            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 32x16/nt-store/xcd", 0, 5});
-            cand.push_back({1, 1, 0, 0, 6, 12, 1, "row-interleaved/6-step 32x16/xcd", 0, 5});
+            // tall strips: six (five) iterations per launch on 64x32 regions held in registers, one exchange of the GR rows after every launch
+            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-store/xcd", 0, 7});
+            cand.push_back({1, 1, 0, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/xcd", 0, 7});
         } else if (strips) {
             const int f = p2 ? 3 : 1;
             if (p2) cand.push_back({1, 1, 1, 0, f, 12, 1, "row-interleaved/3-step sliding 64-column/nt-store", 1});
@@ -849,6 +875,8 @@ int choose_plan(lbm_ctx* c) {
             cand.push_back({1, 1, 0, 1, f, 12, 1, "row-interleaved/3-step 64x12/alternate/xcd"});
         } else {
             if (p2) cand.push_back({1, 1, 1, 0, 4, 8, 1, "row-interleaved/4-step 64x8/nt-store/xcd"});
+            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-store/xcd", 0, 7});   // k_stepc_col
+            cand.push_back({1, 1, 1, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/nt-store/xcd", 0, 6});
             cand.push_back({1, 1, 1, 0, 5, 12, 1, "row-interleaved/5-step 32x16/nt-store/xcd", 0, 4});   // two 512-thread blocks per CU (fp64)
             cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 32x16/nt-store/xcd", 0, 5});
             cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x16/nt-store/xcd", 0, 1});
@@ -867,6 +895,7 @@ int choose_plan(lbm_ctx* c) {
         }
         if (!strips) {
             if (p2) cand.push_back({0, 0, 1, 0, 4, 8, 1, "planar/4-step 64x8/nt-store/xcd"});
+            cand.push_back({0, 0, 1, 0, 6, 12, 1, "planar/6-step 64x32 in registers/nt-store/xcd", 0, 7});
             cand.push_back({0, 0, 1, 0, 5, 12, 1, "planar/5-step 32x16/nt-store/xcd", 0, 4});
             if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 1, "planar/3-step sliding 64-column/nt-store", 1});
             if (p2) cand.push_back({0, 0, 0, 0, 3, 12, 1, "planar/3-step sliding 64-column", 1});
@@ -1788,8 +1817,9 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "nt") c->use_nt = (int)value ? 1 : 0;
     else if (k == "fuse") { if (value < 1 || value > 4) return fail(LBM_ERR_ARG, "fuse must be 1, 2, 3 or 4 (4: tile kernel, no strip faces)"); c->fuse = (int)value; c->deep = 0; }
     else if (k == "deep") {     // k_stepd_tile: 1: 6 iterations on 64x16 tiles, 2: 7 on 64x16, 3: 8 on 32x32 (1024 threads);
-                                // 4 / 5: 5 / 6 iterations on 32x16 tiles (512 threads). Whole-domain launches only.
-        if (value < 0 || value > 5) return fail(LBM_ERR_ARG, "deep must be 0..5");
+                                // 4 / 5: 5 / 6 iterations on 32x16 tiles (512 threads); k_stepc_col (registers): 6 / 7:
+                                // 5 / 6 iterations on 64x32 regions. 2 and 3: whole-domain launches only.
+        if (value < 0 || value > 7) return fail(LBM_ERR_ARG, "deep must be 0..7");
         c->deep = (int)value;
         if (c->deep) { c->fuse = deep_depth(c->deep); c->slide = 0; }
     }
@@ -1841,7 +1871,8 @@ const char* lbm_kernel_name(const lbm_ctx* c) {
     const char* t = c->p.precision == LBM_PRECISION_F32 ? "float" : "double";
     const char* nt = c->use_nt ? "true" : "false";
     const int ar = c->arith;
-    if (c->fuse > 2 && c->deep) snprintf(name, sizeof(name), "k_stepd_tile<%s,%s,%d,%s,true,%d>", t, deep_tile(c->deep), deep_depth(c->deep), nt, ar);
+    if (c->fuse > 2 && deep_is_col(c->deep)) snprintf(name, sizeof(name), "k_stepc_col<%s,%d,%d,%d,%s,%d>", t, COL_R, COL_NW, deep_depth(c->deep), nt, ar);
+    else if (c->fuse > 2 && c->deep) snprintf(name, sizeof(name), "k_stepd_tile<%s,%s,%d,%s,true,%d>", t, deep_tile(c->deep), deep_depth(c->deep), nt, ar);
     else if (c->fuse > 1 && c->slide) snprintf(name, sizeof(name), "k_step_slide<%s,%d,6,%s,%d>", t, c->fuse, nt, ar);
     else if (c->fuse == 4) snprintf(name, sizeof(name), "k_step4_tile<%s,8,%d,%s,%s,%d>", t, c->esize == 8 ? 1024 : 512, nt, c->xcd ? "true" : "false", ar);
     else if (c->fuse > 1) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%s,%s,%d>", c->fuse, t, c->pair_ty,

@@ -62,24 +62,30 @@ __device__ __forceinline__ bool unstable_if(const T (&f)[Q], bool valid) {
     return bad;
 }
 
-template <typename T, int R, int NW, int D, bool NT, bool XCD, int AR = AR_STRICT>
+// Tile walk: blocks are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2) in index order; here every XCD walks
+// one contiguous run of the row-major tile order instead, so that x-neighbours — which share the lines at their common
+// edge — meet in the same L2 at the same time and every XCD streams whole lattice rows (149.6 -> 161.7 GLUPS at 4096x1024
+// fp64). A band-major walk (8..37 tile columns per band, so that y-neighbours meet in L2 too) was measured and is gone:
+// 141-147 GLUPS — a tile then touches 300 sub-rows that its XCD's other tiles do not share, and the TLB / DRAM-page
+// locality of the row-interleaved layout is lost (profiles/r03/README.md).
+// The grid is one-dimensional: cdiv(nx, OW) * (bands of both row ranges) blocks, rounded up to a multiple of 8.
+template <typename T, int R, int NW, int D, bool NT, int AR = AR_STRICT>
 __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_col(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int H = R * NW, HW = D - 1, OW = 64 - 2 * HW, OH = H - 2 * HW, LW = 64 + 2;
-    static_assert(D >= 2 && D <= GR && OH >= 1 && R >= 2, "a strip's ghost rows go GR deep");
+    static_assert(D >= 2 && OH >= 1 && R >= 2, "(D <= GR on a strip: its ghost rows go GR deep — the host's business)");
     // exchange buffer: per wave the three north-going populations of its top row and the three south-going ones of its
     // bottom row; slots 0 and NW+1 stand for the neighbours the first / last wave does not have (never written: garbage
     // for cells that are garbage anyway); one pad column on each side for the diagonal reads at lane -/+ 1
     __shared__ T xbuf[2][NW + 2][6][LW];
     const int lane = (int)threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (XCD) {
-        const int nb = gridDim.x * gridDim.y;
-        int b = by * gridDim.x + bx;
-        if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;
-        by = b / gridDim.x; bx = b - by * gridDim.x;
-    }
-    if (a.reverse) by = (int)gridDim.y - 1 - by;
+    const int nbx = (a.nx + OW - 1) / OW, nby = (a.y_cnt + OH - 1) / OH + (a.y_cnt2 + OH - 1) / OH, nb = nbx * nby;
+    int b = blockIdx.x;
+    { const int per = (int)gridDim.x >> 3; b = (b & 7) * per + (b >> 3); }                   // gridDim.x is a multiple of 8
+    if (b >= nb) return;                                                                      // (whole block: no barrier is left waiting)
+    int by = b / nbx;
+    const int bx = b - by * nbx;
+    if (a.reverse) by = nby - 1 - by;
     int y_end;
     const int Yo = band_origin(a, by, OH, y_end);          // first output row / column of this block
     const int Xo = bx * OW;
@@ -158,12 +164,13 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
             for (int j = 0; j < R; ++j) {
                 const int ry = ry0 + j;
                 const T n2 = g[j][2], n5 = g[j][5], n6 = g[j][6];       // this row's north-going values, for row j+1
+                if (ry >= L - 1 && ry <= H - L) {                       // (wave-uniform) rows outside hold garbage from here on
                 T f[Q];
                 f[0] = g[j][0]; f[1] = from_left(g[j][1]); f[3] = from_right(g[j][3]);
                 f[2] = p2; f[5] = p5; f[6] = p6;
                 if (j < R - 1) { f[4] = g[j + 1][4]; f[7] = from_right(g[j + 1][7]); f[8] = from_left(g[j + 1][8]); }
                 else { f[4] = h4; f[7] = h7; f[8] = h8; }
-                const bool valid = lane_ok && ry >= L - 1 && ry <= H - L;
+                const bool valid = lane_ok;
                 const int y = Yr + ry, yg = a.y_start + y;
                 bool store = L == D && lane >= HW && lane < 64 - HW && ry >= HW && ry < H - HW;
                 if (LEAN) {
@@ -180,7 +187,6 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
                         store = store && y < y_end && !(near_cyl && is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2));
                     }
                 }
-                if (j < R - 1) { p2 = n2; p5 = from_left(n5); p6 = from_right(n6); }   // row j+1 pulls them from this row
                 if (L < D) {
 #pragma unroll
                     for (int i = 0; i < Q; ++i) g[j][i] = f[i];
@@ -199,6 +205,8 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
                         }
                     }
                 }
+                }
+                if (j < R - 1) { p2 = n2; p5 = from_left(n5); p6 = from_right(n6); }   // row j+1 pulls them from this row
             }
             if (badl) atomicMin(a.unstable_t, a.t + L - 1);
         };

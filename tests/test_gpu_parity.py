@@ -54,6 +54,10 @@ PLANS = {
     # five / six iterations per launch on 32x16 tiles with 512-thread blocks (two per CU in fp64: what a large grid's measurement picks)
     "rowil-half5-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=4),
     "planar-half6": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=5),
+    # five / six iterations per launch with the lattice held in registers (k_stepc_col: 64x32 regions, DPP x-shifts, six LDS
+    # values per wave and level; round 3's production kernel — what a large grid's measurement and the strip rule pick)
+    "rowil-col5-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=6),
+    "planar-col6-alt": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, pair_ty=8, xcd=1, deep=7),
     # contracted collision arithmetic (option "arith" 1: FMA + one reciprocal, what the reference's -ffast-math -mfma build
     # permits): not bit-identical to the strict oracle, held to the north-star tolerance 1e-10 like every other plan
     "fast-auto": dict(arith=1),
@@ -67,6 +71,8 @@ PLANS = {
     "fast-rowil-deep7": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=2, arith=1),
     "fast-rowil-half5": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=4, arith=1),
     "fast-planar-deep8": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=3, arith=1),
+    "fast-rowil-col6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
+    "fast-planar-col5": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=6, arith=1),
 }
 FAST = [k for k, v in PLANS.items() if v and v.get("arith")]
 
@@ -83,7 +89,7 @@ def fused_depth(plan_opts, steps_left, done, of):
     deep = (plan_opts or {}).get("deep", 0)
     if deep:
         maxd = 3                                     # what is left of a segment goes to the three-/two-iteration kernels
-        depths = {1: (6,), 4: (6, 5), 5: (6, 5)}.get(deep, ())      # a strip's ghost rows go six deep: no 7 / 8
+        depths = {1: (6,), 4: (6, 5), 5: (6, 5), 6: (6, 5), 7: (6, 5)}.get(deep, ())      # a strip's ghost rows go six deep: no 7 / 8
         for d in depths:
             if steps_left >= d + 1 and all(of <= 0 or (done + j) % of != 0 for j in range(1, d)):
                 return d
@@ -366,7 +372,7 @@ def test_overlap_choreography_with_loopback_halo(lbm, pair):
 
 @pytest.mark.parametrize("overlap,deep", [(1, 1), (0, 1), (1, 0), (0, 0), (2, 1), (2, 0)])
 @pytest.mark.parametrize("plan", ["rowil-fuse3-12-nt-xcd", "rowil-slide3", "rowil-site-nt", "fast-rowil-slide2",
-                                  "rowil-half5-nt", "fast-rowil-half5", "rowil-deep6-nt"])
+                                  "rowil-half5-nt", "fast-rowil-half5", "rowil-deep6-nt", "rowil-col5-nt", "fast-rowil-col6"])
 def test_group_of_strips_on_one_device_matches_single_domain_bitwise(lbm, plan, overlap, deep):
     """In-process strips (lbm_group_*, the transport `lbm_solver --gpus N` uses) with the production choreography: edge
     bands on the side stream, every strip PULLING its neighbours' edge rows with exactly the pointers / offsets / counts
@@ -401,7 +407,7 @@ def test_group_of_strips_on_one_device_matches_single_domain_bitwise(lbm, plan, 
             g.ctxs[0].step(1, 0)
 
 
-@pytest.mark.parametrize("plan", [None, "rowil-half5-nt", "rowil-deep6-nt", "rowil-deep8-nt"])
+@pytest.mark.parametrize("plan", [None, "rowil-half5-nt", "rowil-deep6-nt", "rowil-deep8-nt", "rowil-col5-nt", "planar-col6-alt"])
 def test_host_staged_strips_calling_patterns(lbm, plan):
     """The MPI-hosted calling pattern of INTEGRATION.md §C: lbm_step(4) = a fused launch of three iterations + a single
     one, then the caller exchanges the edge rows — on contexts that measured their own plan (None: large enough to time the
@@ -440,8 +446,8 @@ def test_host_staged_strips_calling_patterns(lbm, plan):
 
 @pytest.mark.parametrize("precision", ["f64", "f32"])
 def test_tall_strips_take_the_deep_plan_by_rule(lbm, precision):
-    """A measured (tune=1) group whose strips have 64 rows or more runs six iterations per launch on 32x16 tiles with one
-    exchange per launch — chosen by rule from the global grid and the strip count, so that every strip (every rank of a
+    """A measured (tune=1) group whose strips have 64 rows or more runs six iterations per launch on 64x32 regions held in
+    registers (k_stepc_col) with one exchange per launch — chosen by rule from the global grid and the strip count, so that every strip (every rank of a
     multi-process run) issues the same launch depths — and reproduces the one-domain run bit for bit (fp64 and fp32)."""
     nx, ny, steps, of = 512, 200, 333, 70
     kw = dict(inlet_velocity=0.05, cylinder_radius=0.1, precision=precision)
@@ -453,7 +459,7 @@ def test_tall_strips_take_the_deep_plan_by_rule(lbm, precision):
     for extra in (dict(), dict(overlap=0), dict(group_threads=0)):
         with lbm.Group(nx, ny, 3, options=extra or None, **kw) as g:
             g.initialise()
-            assert all("6-step 32x16" in m.plan() for m in g.ctxs), [m.plan() for m in g.ctxs]
+            assert all("6-step 64x32 in registers" in m.plan() for m in g.ctxs), [m.plan() for m in g.ctxs]
             g.step(steps, of)
             assert g.first_unstable_step() == -1
             assert np.array_equal(g.populations("f_next"), w_fn)
@@ -522,6 +528,8 @@ def test_checkpoint_restart_is_bit_exact(lbm, tmp_path):
     ("rowil-half5-nt", 20, 0, 0, 5),        # 5+5+5+4 and the single last iteration of a call that may be read back
     ("rowil-half5-nt", 24, 10, 1, 5),       # force outputs at 10 and 20 end the fused segments: 5+5 | 5+5 | 4
     ("rowil-fuse3-12-nt-xcd", 20, 0, 1, 6), # 4+4+3+3+3+3
+    ("rowil-col5-nt", 22, 0, 1, 4),         # 6+6+5+5: the register-column family uses both of its depths too
+    ("fast-rowil-col6", 20, 0, 0, 5),       # 5+5+5+4 and the single last iteration
 ])
 def test_a_call_is_split_into_full_rate_launches(lbm, plan, steps, of, trailing, launches):
     """plan_launch: the iterations of a call (between force outputs) are split into the cheapest sequence of the depths the
