@@ -6,22 +6,27 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one loop body of Solver::run (exchange + stream + BCs + stability + collision) over the whole lattice; the
-library fuses up to three (four on a single strip) consecutive steps into one kernel launch (intermediate states in LDS). Workload at every N:
-BASELINE.json configs[2], the 4096x1024 fp64 cylinder at Re=200 (tau=0.6, u_in=0.06510417) — the grid the metric is
-quoted on ("4096x1024 D2Q9 at 1/2/4/8 GPUs"), so N>1 is STRONG scaling: the rows are cut into N strips, one process per
-GPU, LBM_HALO_ROWS edge rows x 9 populations per face exchanged with RCCL send/recv once per two launches (schedule
-measured at initialise). Populations are resident in HBM before the timed region; nothing is copied to the host inside
-it and no output (forces/VTK) step falls inside it.
+library fuses up to six consecutive steps into one kernel launch (k_stepc_col: the lattice of a 64x32 region stays in
+registers between them). Workload at every N: BASELINE.json configs[2], the 4096x1024 fp64 cylinder at Re=200 (tau=0.6,
+u_in=0.06510417) — the grid the metric is quoted on ("4096x1024 D2Q9 at 1/2/4/8 GPUs"), so N>1 is STRONG scaling: the
+rows are cut into N strips, one process per GPU, LBM_HALO_ROWS edge rows x 9 populations per face exchanged with RCCL
+send/recv once per launch of six iterations (schedule measured at initialise). Populations are resident in HBM before
+the timed region; nothing is copied to the host inside it and no output (forces/VTK) step falls inside it.
 
 Runtime hygiene: liblbm_hip.so is loaded BEFORE torch (and torch only at N>1, for the gloo rendezvous of the 128-byte
 ncclUniqueId and the barriers; no torch.cuda call is made), so that the process binds the ROCm RCCL/HIP the library was
 built and tested against, not the copies bundled with the torch wheel; the versions actually bound are printed in the
 JSON line. The timed region is bracketed by lbm_sync (both streams of the library) + a gloo barrier on both sides.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (live HIP-event kernel time on the
-library's own stream; `frac` = measured HBM bytes per launch / time / 8 TB/s, the 144 B-per-update figure separately) and,
-at N=1, `cpu_baseline` (the reference binary oracle/_ref/ref_driver if it runs on this host, else the oracle port;
-bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement). `roofline` (dominant kernel, live HIP-event time on the
+library's own stream): `achieved` / `frac` price every lattice update at SURVEY §8(d)'s 144 B (72 B fp32) exactly as the
+contract defines them — above 1 for a launch that fuses d iterations, which moves ~1/d of that; `frac_hbm_measured` = the HBM
+bytes the kernel really moved (committed PMC passes, profiles/traffic.json) / time / 8 TB/s; `frac_valu` = the same passes'
+vector instructions against the chip's issue rate; `bound` = whichever of the two is nearer its ceiling. `sustained` = a
+second, longer window of the same context. At N=1 also `cpu_baseline` (the reference binary oracle/_ref/ref_driver if it
+runs on this host, else the oracle port; bounded sample), `other_arithmetic` and `single_precision_variant` (BASELINE.json
+configs[4] on this GPU with its MLUPS-per-GB/s beside the fp64 figure). At N>1 `strips.parity`: a second short run compared
+bit for bit with a one-GPU run of the whole grid.
 """
 import argparse
 import importlib
@@ -38,6 +43,9 @@ if ROOT not in sys.path:
 PKG = "highperformancecomputing-latticeboltzmannmethod_amd"
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# vector-issue ceiling of the chip: 256 CUs x 4 SIMDs, a wave64 instruction takes 4 cycles in fp64 (16 lanes/clk/SIMD: 78.6
+# TFLOP/s fp64 vector peak) and 2 in fp32 (32 lanes/clk), 2.4 GHz  ->  lane-instructions per second
+VALU_LANE_RATE = {"f64": 256 * 4 * 16 * 2.4e9, "f32": 256 * 4 * 32 * 2.4e9}
 BYTES_PER_LUP = {"f64": 144, "f32": 72}   # 9 loads + 9 stores per lattice update
 CONFIGS = {(1024, 256, "f64", 100.0): "configs[1]", (4096, 1024, "f64", 200.0): "configs[2]", (8192, 2048, "f64", 200.0): "configs[3]",
            (16384, 4096, "f32", 200.0): "configs[4]"}
@@ -105,8 +113,8 @@ def cpu_baseline(nx, ny, u_in, budget_s=12.0):
 
 
 def measured_traffic(nx, local_ny, precision, kernel, layout=""):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json; FETCH_SIZE and
-    WRITE_SIZE cannot be collected inside a timed run). Returns (bytes | None, note)."""
+    """The committed counter passes of the dominant kernel on this grid (profiles/traffic.json: FETCH_SIZE, WRITE_SIZE and SQ
+    counters cannot be collected inside a timed run). Returns (entry | None, note)."""
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         tj = json.load(open(tfile))
@@ -116,8 +124,58 @@ def measured_traffic(nx, local_ny, precision, kernel, layout=""):
     ents = [e for e in (tj.get(key) or []) if e.get("kernel", "").replace(" ", "") == kernel.replace(" ", "")]
     ents.sort(key=lambda e: e.get("layout", "") != layout)      # the pass taken in the same layout first
     if ents:
-        return ents[0].get("hbm_bytes_per_launch"), ents[0].get("source", "profiles/traffic.json")
-    return None, f"no FETCH_SIZE/WRITE_SIZE pass committed for {key} with {kernel} (profiles/traffic.json)"
+        return ents[0], ents[0].get("source", "profiles/traffic.json")
+    return None, f"no counter pass committed for {key} with {kernel} (profiles/traffic.json)"
+
+
+def plan_depth_of(kernel):
+    m = re.match(r"k_step(\d)_tile|k_step_slide<\w+,(\d)|k_stepd_tile<\w+,\d+,\d+,(\d)|k_stepc_col<\w+,\d+,\d+,(\d)", kernel)
+    return int(next(g for g in m.groups() if g)) if m else 1
+
+
+def roofline_of(lbm, ctx, nx, local_ny, precision, kernel_ms, launches, iterations, steps):
+    """The `roofline` object for the dominant kernel of a timed call (see the module docstring)."""
+    bpl = BYTES_PER_LUP[precision]
+    ipl = iterations / max(launches, 1)
+    launch_bytes = int(nx * local_ny * bpl * ipl)          # SURVEY §8(d): 144 B (72 B) x the lattice updates of one launch
+    kernel = ctx.kernel_name()
+    ent, tnote = measured_traffic(nx, local_ny, precision, kernel, ctx.plan().split("/")[0])
+    plan_depth = plan_depth_of(kernel)
+    scale = ipl / plan_depth          # a short call mixes launch depths (20 = 5+5+5+5 on a six-iteration plan): the counter
+    if abs(scale - 1.0) > 0.01:       # passes belong to the plan's kernel at its own depth
+        tnote += f"; scaled by {ipl:.3f}/{plan_depth} (mixed launch depths in a {steps}-step call)"
+    secs = kernel_ms * 1e-3
+    achieved = launch_bytes / secs / 1e9 if secs > 0 else 0.0
+    r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel, "kernel_ms": round(kernel_ms, 5),
+         "algorithmic_bytes_per_launch": launch_bytes, "iterations_per_launch": round(ipl, 4),
+         "frac_144B": round(achieved / HBM_PEAK_GBS, 4), "frac_hbm_measured": None, "frac_valu": None,
+         "frac_hbm_fused_minimum": round((launch_bytes / ipl) / secs / 1e9 / HBM_PEAK_GBS, 4) if secs > 0 else None}
+    if ent:
+        traffic = int(ent["hbm_bytes_per_launch"] * scale)
+        gbs = traffic / secs / 1e9
+        r.update(traffic=traffic, hbm_gbs_measured=round(gbs, 1), frac_hbm_measured=round(gbs / HBM_PEAK_GBS, 4),
+                 hbm_bytes_per_update=round(traffic / (nx * local_ny * ipl), 2),
+                 mlups_per_gbs=round(nx * local_ny * ipl / secs / 1e6 / gbs, 2), traffic_source=tnote)
+        if ent.get("valu_insts_per_launch"):
+            lane = ent["valu_insts_per_launch"] * 64.0 / (nx * local_ny * plan_depth)      # lane-instructions per lattice update
+            ceil = VALU_LANE_RATE[precision] / lane / 1e6                                     # MLUPS if vector issue were the only limit
+            r.update(valu_lane_instr_per_update=round(lane, 1), valu_ceiling_mlups=round(ceil, 0),
+                     frac_valu=round(nx * local_ny * ipl / secs / 1e6 / ceil, 4),
+                     lds_insts_per_update=round(ent.get("lds_insts_per_launch", 0) * 64.0 / (nx * local_ny * plan_depth), 2))
+        if r["frac_valu"] and r["frac_valu"] > r["frac_hbm_measured"]:
+            r["bound"] = "valu"      # (the contract's vocabulary has no word for it: vector issue, no MFMA on this path)
+    else:
+        r["traffic_source"] = tnote
+    r["note"] = ("achieved/frac = frac_144B: SURVEY 8(d)'s algorithmic bytes (144 B fp64 / 72 B fp32 per lattice update) x the updates of "
+                 "one launch / the kernel's live launch time / 8 TB/s — ABOVE 1 because a launch fuses iterations_per_launch "
+                 "iterations in registers and so moves ~1/d of the unfused bytes; it is the figure to hold against an unfused "
+                 "kernel's roofline (north_star's 70 % = 0.70). frac_hbm_measured = bytes the kernel really moved (PMC FETCH_SIZE x2 + "
+                 "WRITE_SIZE, separate passes, profiles/) / time / 8 TB/s (the streaming ceiling measured on this part is 6.0-6.3 TB/s "
+                 "= 0.75-0.79); frac_valu = vector lane-instructions per update from the SQ pass against 1024 SIMDs x 16 (fp64) or "
+                 "32 (fp32) lanes/clk x 2.4 GHz; bound = the larger of the two; frac_hbm_fused_minimum = one read + one write of the "
+                 "lattice per launch, the least any d-iteration launch can move")
+    return r
 
 
 def main():
@@ -137,6 +195,7 @@ def main():
     ap.add_argument("--set", action="append", default=[], help="library option key=value (lbm_set_option), e.g. slide=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-arith", action="store_true", help="skip the run in the other arithmetic mode (profiler passes)")
+    ap.add_argument("--no-f32-variant", action="store_true", help="skip the single-precision variant (BASELINE.json configs[4]) beside the headline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -200,14 +259,23 @@ def main():
     dt = time.perf_counter() - t0
     ms_total, launches, iterations = ctx.last_step_stats()
     kernel_ms = ms_total / max(launches, 1)            # mean duration of one launch of the dominant kernel
+    # `sustained`: a second, longer window of the same context (the driver's K may be as short as 20 steps = 4 launches,
+    # which a boosting clock flatters by ~5 %): at least 3000 steps / 80 ms
+    sus_steps = max(3000, args.steps) if world == 1 else max(1200, args.steps)
+    t1 = time.perf_counter()
+    ctx.step(sus_steps, 0)
+    fence()
+    dt_sus = time.perf_counter() - t1
+    s_ms, s_launches, s_iterations = ctx.last_step_stats()
     compute_only_ms = None
     if world > 1:
-        tt = torch.tensor([dt, kernel_ms], dtype=torch.float64)
+        tt = torch.tensor([dt, kernel_ms, dt_sus], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, kernel_ms = float(tt[0]), float(tt[1])
+        dt, kernel_ms, dt_sus = float(tt[0]), float(tt[1]), float(tt[2])
     bad = ctx.first_unstable_step()
     if bad != -1:
         sys.exit(f"simulation unstable at timestep {bad}: result invalid")
+    parity = None
     if world > 1:
         # what the halo traffic costs: the same launches with the exchange skipped (diagnostic pass, results discarded)
         n = max(60, min(args.steps, 600))
@@ -221,8 +289,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         compute_only_ms = float(tt[0])
         ctx.set_option("skip_exchange", 0)
+        parity = strip_parity(lbm, ctx, dist, rank, world, nx, ny_total, local_ny, u_in, args, device)
 
     other = None
+    spv = None
     if world == 1 and not args.no_other_arith:
         # the same workload in the OTHER arithmetic mode, same harness, reported beside the headline (not part of `value`)
         oa = "strict" if args.arith == "contracted" else "contracted"
@@ -232,36 +302,24 @@ def main():
             c2.step(args.warmup, 0)
             c2.sync()
             t1 = time.perf_counter()
-            c2.step(args.steps, 0)
+            c2.step(sus_steps, 0)
             c2.sync()
             dt2 = time.perf_counter() - t1
-            other = {"arithmetic": oa, "value": round(nx * ny_total * args.steps / dt2 / 1e6, 1), "unit": "MLUPS",
-                     "kernel": c2.kernel_name(), "plan": c2.plan(), "unstable": c2.first_unstable_step()}
+            ub = c2.first_unstable_step()
+            if ub != -1:
+                sys.exit(f"the {oa} run went unstable at timestep {ub}: result invalid")
+            other = {"arithmetic": oa, "value": round(nx * ny_total * sus_steps / dt2 / 1e6, 1), "unit": "MLUPS", "steps": sus_steps,
+                     "kernel": c2.kernel_name(), "plan": c2.plan(), "unstable": ub}
+    if world == 1 and not args.no_f32_variant and (nx, ny_total, args.precision) == (4096, 1024, "f64"):
+        spv = single_precision_variant(lbm, device, args)
 
     if rank == 0:
         cells = nx * ny_total
         mlups = cells * args.steps / dt / 1e6
-        bpl = BYTES_PER_LUP[args.precision]
-        ipl = iterations / max(launches, 1)
-        # dominant kernel: one launch advances this rank's strip by `ipl` iterations (3 when three timesteps are fused
-        # through LDS); algorithmic bytes per launch = lattice updates per launch x 144 B (fp64) / 72 B (fp32)
-        launch_bytes = int(nx * local_ny * bpl * ipl)
-        kernel = ctx.kernel_name()
-        traffic, tnote = measured_traffic(nx, local_ny, args.precision, kernel, ctx.plan().split("/")[0])
-        equiv = launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        m = re.match(r"k_step(\d)_tile|k_step_slide<\w+,(\d)|k_stepd_tile<\w+,\d+,\d+,(\d)", kernel)
-        plan_depth = int(m.group(1) or m.group(2) or m.group(3)) if m else 1
-        if traffic and abs(ipl - plan_depth) > 0.01 * plan_depth:
-            # a short call mixes launch depths (e.g. 20 = 4+4+3+3+3+3, or a two-iteration tail): the PMC figure belongs to the
-            # plan's kernel at its own depth; scale it to the mean depth of the timed launches
-            traffic = int(traffic * ipl / plan_depth)
-            tnote += f"; scaled by {ipl:.3f}/{plan_depth} (mixed launch depths in a {args.steps}-step call)"
-        if traffic:
-            achieved, basis = traffic / (kernel_ms * 1e-3) / 1e9, "measured HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE; " + tnote + ") / live launch time"
-        else:   # the least a fused launch can move: read P_t once, write P_{t+d} once
-            achieved, basis = (launch_bytes / ipl) / (kernel_ms * 1e-3) / 1e9, "fused minimum (one read + one write of the lattice per launch) / live launch time; " + tnote
         hr = lbm.Context.HALO_ROWS
         cfg_name = CONFIGS.get((nx, ny_total, args.precision, float(args.re)))
+        kernel = ctx.kernel_name()
+        roof = roofline_of(lbm, ctx, nx, local_ny, args.precision, kernel_ms, launches, iterations, args.steps)
         line = {
             "metric": f"MLUPS ({'fp64' if args.precision == 'f64' else 'fp32'})", "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
@@ -278,25 +336,22 @@ def main():
                        "kernel": kernel, "plan": ctx.plan(), "build_id": lbm.build_id(),
                        "runtime": {"rccl": versions["rccl"], "hip_runtime": versions["hip_runtime"], "hip_driver": versions["hip_driver"],
                                    "torch_loaded": torch is not None}},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "basis": basis,
-                         "kernel": kernel, "kernel_ms": round(kernel_ms, 5),
-                         "algorithmic_bytes_per_launch": launch_bytes, "iterations_per_launch": round(ipl, 4),
-                         "equiv_144B_gbs": round(equiv, 1), "equiv_144B_frac": round(equiv / HBM_PEAK_GBS, 4),
-                         "limiter": "not HBM: a launch fuses several iterations through LDS precisely to move fewer bytes per update "
-                                    "(DESIGN.md §3: VALU ~53 % busy, LDS ~34 %, HBM ~0.5 of peak on the six-iteration kernel; the "
-                                    "barrier-separated LDS/VALU phases of a block bound it)" if plan_depth >= 4 else
-                                    "HBM first (the kernel moves 0.6-0.8 of the peak), then the exposed latency of its load phase",
-                         "note": "frac = HBM bytes actually moved per launch / time / peak (<= 1). equiv_144B_* price every lattice update at "
-                                 "the unfused 144 B (72 B fp32): a launch that fuses d iterations through LDS moves ~1/d of that, so the "
-                                 "equivalent figure can exceed the peak; it is the number to compare with an unfused kernel's roofline"},
+            "sustained": {"value": round(cells * sus_steps / dt_sus / 1e6, 1), "unit": "MLUPS", "steps": sus_steps,
+                          "ms_per_step": round(dt_sus / sus_steps * 1e3, 5),
+                          "note": "a second, longer window of the same context, same fences; `value` above is the contract's K-step window"},
+            "roofline": roof,
         }
         if world > 1:
             line["strips"] = {"nranks": world, "schedule": ctx.strip_schedule(),
                               "ms_per_step_compute_only": round(compute_only_ms, 5),
                               "ms_per_step_exchange_exposed": round(dt / args.steps * 1e3 - compute_only_ms, 5)}
+            line["strips"].update(parity)
         if other is not None:
             line["other_arithmetic"] = other
+        if spv is not None:
+            if roof.get("mlups_per_gbs"):
+                spv["mlups_per_gbs_fp64_headline"] = roof["mlups_per_gbs"]
+            line["single_precision_variant"] = spv
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(nx, ny_total, u_in)
         print(json.dumps(line), flush=True)
@@ -304,6 +359,78 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def single_precision_variant(lbm, device, args):
+    """north_star / BASELINE.json configs[4]: the fp32 variant (16384x4096, Re=200) on this one GPU (2 x 2.4 GB), with its
+    MLUPS per GB/s of HBM traffic to hold beside the fp64 figure (the 8-GPU strip run of that grid is the driver's)."""
+    nx, ny = 16384, 4096
+    u_in = 200.0 * ((0.6 - 0.5) / 3.0) / (2.0 * 0.05 * ny)
+    steps = 600
+    try:
+        with lbm.Context(nx, ny, tau=0.6, inlet_velocity=u_in, precision="f32", device=device,
+                         options=dict(arith=1 if args.arith == "contracted" else 0, trailing_pair=1)) as c:
+            c.initialise()
+            c.set_option("timing", 1)
+            c.step(60, 0)
+            c.sync()
+            t1 = time.perf_counter()
+            c.step(steps, 0)
+            c.sync()
+            dt = time.perf_counter() - t1
+            if c.first_unstable_step() != -1:
+                return {"error": "unstable"}
+            ms_total, launches, iterations = c.last_step_stats()
+            roof = roofline_of(lbm, c, nx, ny, "f32", ms_total / max(launches, 1), launches, iterations, steps)
+            out = {"workload": f"D2Q9-BGK cylinder Re=200, {nx}x{ny} f32 (BASELINE.json configs[4]) on ONE GPU", "value": round(nx * ny * steps / dt / 1e6, 1),
+                   "unit": "MLUPS", "steps": steps, "kernel": c.kernel_name(), "plan": c.plan()}
+            for k in ("frac_144B", "frac_hbm_measured", "frac_valu", "hbm_gbs_measured", "hbm_bytes_per_update", "mlups_per_gbs", "bound"):
+                out[k] = roof.get(k)
+            return out
+    except Exception as e:      # (a GPU that cannot hold 2 x 2.4 GB beside the headline context: report, do not fail the bench)
+        return {"error": str(e)[:200]}
+
+
+def strip_parity(lbm, ctx, dist, rank, world, nx, ny_total, local_ny, u_in, args, device):
+    """Outside the timed region: a SECOND short run from iteration 0 on the strips (same communicator, same measured plan and
+    schedule: lbm_initialise again), whose post-collision populations are compared row by row, bit for bit, with a one-GPU
+    run of the whole grid made by rank 0 on its own device — strips must reproduce the one-rank result exactly, in either
+    arithmetic mode (tests/), so the first N>1 line proves exchange_rccl's nranks>1 branch (csrc/lbm_hip.hip; replaces the
+    reference's Grid::exchange_ghost_cells, LBMGrid.h:249-283) by itself."""
+    import numpy as np
+    its = 24
+    ctx.set_option("trailing_pair", 0)      # the call ends on a single iteration: f_next can be read back
+    ctx.initialise()                         # collective (the strip schedule is re-measured): every rank is here
+    ctx.step(its, 0)
+    ctx.sync()
+    fn = ctx.populations("f_next")[1:-1]    # (local_ny, nx+2, 9): the strip's own rows, ghost columns included
+    sums = np.ascontiguousarray(fn).view(np.uint64).reshape(local_ny, -1).sum(axis=1, dtype=np.uint64)      # exact per-row checksum of the bit patterns
+    info = dict(rank=rank, y_start=rank * local_ny, rows=local_ny, plan=ctx.plan(), schedule=ctx.strip_schedule(),
+                kernel=ctx.kernel_name(), unstable=ctx.first_unstable_step(), sums=sums.tolist())
+    gathered = [None] * world
+    dist.all_gather_object(gathered, info)
+    if rank != 0:
+        return {}
+    with lbm.Context(nx, ny_total, tau=0.6, inlet_velocity=u_in, precision=args.precision, device=device,
+                     options=dict(arith=1 if args.arith == "contracted" else 0)) as whole:
+        whole.initialise()
+        whole.step(its, 0)
+        wf = whole.populations("f_next")[1:-1]
+        wsums = np.ascontiguousarray(wf).view(np.uint64).reshape(ny_total, -1).sum(axis=1, dtype=np.uint64)
+        wplan = whole.plan()
+    verdict = "bit-equal"
+    for g in sorted(gathered, key=lambda g: g["rank"]):
+        got = np.array(g["sums"], dtype=np.uint64)
+        ref = wsums[g["y_start"]:g["y_start"] + g["rows"]]
+        diff = np.nonzero(got != ref)[0]
+        if diff.size:
+            verdict = f"MISMATCH: rank {g['rank']} first differs at global row {g['y_start'] + int(diff[0])} ({diff.size} of {g['rows']} rows)"
+            break
+    return {"parity": verdict,
+            "parity_basis": f"{its} iterations from initialise on the {world} strips vs one whole-grid context on rank 0's GPU ({wplan}); "
+                            f"per-row checksums of the f_next bit patterns, gathered over gloo",
+            "per_rank": [dict(rank=g["rank"], rows=g["rows"], plan=g["plan"], schedule=g["schedule"], kernel=g["kernel"],
+                              unstable=g["unstable"]) for g in sorted(gathered, key=lambda g: g["rank"])]}
 
 
 if __name__ == "__main__":

@@ -14,6 +14,9 @@
 #include <cstring>
 #include <atomic>
 #include <barrier>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -50,6 +53,70 @@ int fail(int code, const char* fmt, ...) {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
+
+// The host threads of an in-process group of strips (lbm_group_link): one per strip beyond the first, created ONCE and parked
+// on a condition variable between lbm_group_step calls (a call used to spawn and join n-1 std::threads: Solver::run issues one
+// call per output chunk, ~1 ms of GPU work at N = 8). Strip 0 is driven by the calling thread. Inside a job the n threads move
+// in lockstep through `sync`; whether a phase aborts is decided ONCE per rendezvous, in the barrier's completion step, from
+// the error state as it stood when the last thread arrived — so every thread takes the same branch and nobody is left
+// waiting at the next rendezvous (a thread that failed after a rendezvous used to make a slower one return early).
+struct GroupPool {
+    struct Snap {
+        GroupPool* p;
+        void operator()() noexcept { p->phase_err = p->err.load(); }
+    };
+    const int n;
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    const std::function<void(int)>* job = nullptr;
+    unsigned long gen = 0;
+    int pending = 0;
+    bool stop = false;
+    std::atomic<int> err{0};
+    int phase_err = 0;                 // written by the barrier's completion step only: the same for every thread of a phase
+    std::mutex emu;
+    std::string msg;
+    std::barrier<Snap> sync;
+    explicit GroupPool(int n_) : n(n_), sync(n_, Snap{this}) {
+        for (int i = 1; i < n; ++i) th.emplace_back([this, i] { loop(i); });
+    }
+    ~GroupPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_job.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void loop(int i) {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen; f = job;
+            }
+            (*f)(i);
+            { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv_done.notify_one(); }
+        }
+    }
+    // run f(0) .. f(n-1), one strip per thread; returns when all are done
+    void run(const std::function<void(int)>& f) {
+        err.store(0); phase_err = 0; msg.clear();
+        { std::lock_guard<std::mutex> lk(mu); job = &f; pending = n - 1; ++gen; }
+        cv_job.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    void report(int rc, const char* text) {
+        if (rc == 0) return;
+        std::lock_guard<std::mutex> lk(emu);
+        if (err.load() == 0) { msg = text; err.store(rc); }
+    }
+    // rendezvous; true: some strip had failed by the time the last one arrived — EVERY thread sees true and leaves
+    bool arrive() { sync.arrive_and_wait(); return phase_err != 0; }
+};
 
 struct lbm_ctx {
     lbm_params p{};
@@ -119,6 +186,7 @@ struct lbm_ctx {
     int group_transport = 0, group_n = 1, group_k = 0;
     int group_threads = 1;   // a group is driven by one host thread per strip (0: the calling thread issues for every strip)
     bool owns_comm = true;
+    std::shared_ptr<GroupPool> pool;   // the group's host threads (shared by its members)
     int edge_rows[2] = {0, 0};   // edge-band heights of the launch in flight (issue_before -> issue_after)
     bool ext_split_pending = false;   // overlap 2: the edge part of the last extended launch is queued on the side stream (ev_edge)
     // host-staged halo staging (device side)
@@ -970,7 +1038,15 @@ int tune_strip_schedule(lbm_ctx* c) {
     const bool multi = c->comm && (c->nranks > 1 || c->loopback == 2);
     snprintf(c->sched_desc, sizeof(c->sched_desc), "overlap=%d deep_halo=%d (%s)", c->overlap, c->deep_halo,
              multi ? "fixed by options" : "default");
-    if (!multi || !c->tune || (c->overlap_pinned && c->deep_pinned) || c->nyl < 4 * GR) return LBM_OK;
+    if (!multi) return LBM_OK;
+    {   // The trials below are COLLECTIVE (send/recv with the neighbours, an all-reduce per schedule): whether they run must be
+        // the same decision on every rank. Strips may differ in height (191 rows over 8 ranks: seven of 24 and one of 23) and,
+        // in principle, in their options, so the decision is reduced over the ranks first: all of them tune, or none does.
+        double go = (c->tune && !(c->overlap_pinned && c->deep_pinned) && c->nyl >= 4 * GR) ? 1.0 : 0.0;
+        int rc = allreduce_doubles(c, &go, 1, 2);      // MIN
+        if (rc) return rc;
+        if (go < 0.5) return LBM_OK;
+    }
     const int keep_overlap = c->overlap, keep_deep = c->deep_halo, keep_tp = c->trailing_pair;
     double best_ms = 1e30;
     int best_o = keep_overlap, best_d = keep_deep, tried = 0;
@@ -1044,21 +1120,13 @@ int do_steps(lbm_ctx** cs, int n, int nsteps, int of) {
     const bool transport = n > 1 || (c0->comm && c0->nranks > 1) || c0->loopback;   // a device transport is attached
     int launches = 0;
     std::vector<Launch> L((size_t)n);
-    if (n > 1 && c0->group_threads) {
+    if (n > 1 && c0->group_threads && c0->pool) {
         // One host thread per strip: a launch costs a strip ~10 runtime calls (kernels, events, copies), which one thread
         // issuing for 8 GPUs in turn cannot hide behind 20 us kernels. Three rendezvous per launch: every strip's
         // ev_edge is recorded before anybody pulls, every pull is queued before anybody records ev_comm / launches the
         // interior, and every ev_comm is recorded before the next launch looks at its neighbours'.
-        std::barrier sync(n);
-        std::atomic<int> err{LBM_OK};
-        std::mutex mu;
-        std::string msg;
-        auto report = [&](int rc) {
-            if (rc == LBM_OK) return;
-            std::lock_guard<std::mutex> lk(mu);
-            if (err.load() == LBM_OK) { msg = g_err; err.store(rc); }
-        };
-        auto worker = [&](int i) {
+        GroupPool& P = *c0->pool;
+        const std::function<void(int)> worker = [&](int i) {
             lbm_ctx* c = cs[i];
             (void)hipSetDevice(c->device);
             for (int k = 0; k < nsteps;) {
@@ -1072,32 +1140,26 @@ int do_steps(lbm_ctx** cs, int n, int nsteps, int of) {
                 }
                 if (!rc) rc = plan_launch(c, nsteps - k, of, transport, true, &L[(size_t)i]);
                 if (!rc) rc = issue_before<T>(c, L[(size_t)i]);
-                report(rc);
-                sync.arrive_and_wait();
-                if (err.load() != LBM_OK) return;
+                P.report(rc, g_err);
+                if (P.arrive()) return;
                 if (L[(size_t)i].depth != L[0].depth || L[(size_t)i].kind != L[0].kind)
-                    report(fail(LBM_ERR_ARG, "the strips of a group disagree on the next launch (different options?)"));
+                    P.report(fail(LBM_ERR_ARG, "the strips of a group disagree on the next launch (different options?)"), g_err);
                 else if (L[0].kind == KIND_EXCHANGE) {
-                    if (c0->group_transport == 0) report(pull_halos<T>(cs, n, i, L[0].dst));
-                    else if (i == 0) report(exchange_group<T>(cs, n, L[0].dst));      // RCCL: one group call, one thread
+                    int rc2 = LBM_OK;
+                    if (c0->group_transport == 0) rc2 = pull_halos<T>(cs, n, i, L[0].dst);
+                    else if (i == 0) rc2 = exchange_group<T>(cs, n, L[0].dst);      // RCCL: one group call, one thread
+                    P.report(rc2, g_err);
                 }
-                sync.arrive_and_wait();
-                if (err.load() != LBM_OK) return;
-                report(issue_after<T>(c, L[(size_t)i]));
-                sync.arrive_and_wait();
-                if (err.load() != LBM_OK) return;
+                if (P.arrive()) return;
+                P.report(issue_after<T>(c, L[(size_t)i]), g_err);
+                if (P.arrive()) return;
                 k += L[(size_t)i].depth;       // (its own copy: strip 0 may already be planning the next launch into L[0])
                 if (i == 0) ++launches;
             }
         };
-        const int t_begin = c0->steps_done;
-        std::vector<std::thread> th;
-        for (int i = 1; i < n; ++i) th.emplace_back(worker, i);
-        worker(0);
-        for (auto& x : th) x.join();
-        if (err.load() != LBM_OK) return fail(err.load(), "%s", msg.c_str());
+        P.run(worker);
+        if (P.err.load() != LBM_OK) return fail(P.err.load(), "%s", P.msg.c_str());
         HIPCHK(hipSetDevice(c0->device));
-        (void)t_begin;
     } else
     for (int k = 0; k < nsteps;) {
         const int t = c0->steps_done;
@@ -1443,8 +1505,18 @@ void lbm_destroy(lbm_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm) ncclCommDestroy(c->comm);
-    for (lbm_ctx* nb : {c->nb_south, c->nb_north})   // a destroyed member leaves its group
-        if (nb) { if (nb->nb_south == c) nb->nb_south = nullptr; if (nb->nb_north == c) nb->nb_north = nullptr; }
+    for (lbm_ctx* nb : {c->nb_south, c->nb_north}) {  // a destroyed member leaves its group
+        if (!nb) continue;
+        // the neighbour's exchange stream may still hold a pull (hipMemcpyPeerAsync) that READS this member's edge rows, and
+        // freeing a buffer only waits for work of this member's own device: drain the neighbour's streams first
+        (void)hipSetDevice(nb->device);
+        if (nb->comm_stream) (void)hipStreamSynchronize(nb->comm_stream);
+        if (nb->stream) (void)hipStreamSynchronize(nb->stream);
+        if (nb->nb_south == c) nb->nb_south = nullptr;
+        if (nb->nb_north == c) nb->nb_north = nullptr;
+    }
+    (void)hipSetDevice(c->device);
+    c->pool.reset();
     void* ptrs[] = {c->buf[0], c->buf[1], c->scratch, c->d_macro, c->d_maxbits, c->d_unstable, c->d_solid_count, c->d_feq,
                     c->d_force_now, c->d_force_log, c->d_halo, c->d_red};
     for (void* q : ptrs)
@@ -1701,12 +1773,15 @@ int lbm_group_link(lbm_ctx** cs, int n, int transport) {
             }
         }
     }
+    std::shared_ptr<GroupPool> pool(new (std::nothrow) GroupPool(n));
+    if (!pool) return fail(LBM_ERR_ALLOC, "out of host memory");
     for (int k = 0; k < n; ++k) {
         cs[k]->nb_south = k > 0 ? cs[k - 1] : nullptr;
         cs[k]->nb_north = k + 1 < n ? cs[k + 1] : nullptr;
         cs[k]->group_transport = transport;
         cs[k]->group_n = n;
         cs[k]->group_k = k;
+        cs[k]->pool = pool;
     }
     return LBM_OK;
 }

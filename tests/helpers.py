@@ -32,3 +32,16 @@ def macro_errors(rho, ux, uy, g_rho, g_ux, g_uy):
     """(err_rho, err_u): rho relative to max|rho|; both velocity components relative to max|u| of the expected field."""
     uscale = float(np.max(np.sqrt(np.asarray(g_ux) ** 2 + np.asarray(g_uy) ** 2)))
     return linf_rel(rho, g_rho), max(linf_rel(ux, g_ux, uscale), linf_rel(uy, g_uy, uscale))
+
+
+def record(name, **values):
+    """Append one measured-error line to gpurun_out/parity_measured.jsonl (merged back from the GPU box; the round's copy is
+    committed under profiles/). Best effort: a read-only tree must not fail a test."""
+    import json
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_measured.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=name, **values)) + "\n")
+    except OSError:
+        pass

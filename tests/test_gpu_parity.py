@@ -11,7 +11,7 @@ import importlib
 import numpy as np
 import pytest
 
-from tests.helpers import golden_params, linf_rel, load_golden, macro_errors
+from tests.helpers import golden_params, linf_rel, load_golden, macro_errors, record
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -469,6 +469,44 @@ def test_tall_strips_take_the_deep_plan_by_rule(lbm, precision):
                 assert abs(fx - wx) <= ftol * max(1.0, abs(wx)) and abs(fy - wy) <= ftol
 
 
+def test_strongly_uneven_strips_under_the_deep_rule(lbm):
+    """The strip rule picks the six-iteration register kernel from ny / strips alone (200 / 3 >= 64), whatever the strips'
+    real heights: strips of 150, 14 and 36 rows — the middle one shorter than one band of tiles, i.e. all edge — must still
+    reproduce the one-domain run bit for bit, with one host thread per strip and with the calling thread issuing for all."""
+    nx, ny, steps, of = 384, 200, 187, 60
+    kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
+    with lbm.Context(nx, ny, options=PLANS["rowil-site-nt"], **kw) as whole:
+        whole.initialise()
+        whole.step(steps, of)
+        w_fn, w_log = whole.populations("f_next"), whole.drain_force_log()
+    for extra in (dict(), dict(group_threads=0, overlap=0)):
+        with lbm.Group(nx, ny, [(0, 150), (150, 14), (164, 36)], options=extra or None, **kw) as g:
+            g.initialise()
+            assert all("6-step 64x32 in registers" in m.plan() for m in g.ctxs), [m.plan() for m in g.ctxs]
+            g.step(steps, of)
+            assert g.first_unstable_step() == -1
+            assert np.array_equal(g.populations("f_next"), w_fn)
+            assert [r[0] for r in g.drain_force_log()] == [r[0] for r in w_log]
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("threads", [1, 0])
+def test_a_failing_strip_is_an_error_not_a_hang(lbm, threads):
+    """A group whose members disagree (one strip pinned to single-iteration launches) must come back from lbm_group_step
+    with an error on every driver — with one host thread per strip the decision to abort is taken once per rendezvous, so no
+    thread is left waiting at a barrier the others never reach — and the group stays usable for teardown."""
+    nx, ny = 256, 120
+    kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
+    opts = dict(PLANS["rowil-fuse3-12-nt-xcd"], group_threads=threads)
+    with lbm.Group(nx, ny, 3, options=opts, **kw) as g:
+        g.ctxs[1].set_option("fuse", 1)
+        g.initialise()
+        with pytest.raises(lbm.LbmError, match="disagree"):
+            g.step(30, 0)
+        with pytest.raises(lbm.LbmError):          # ... and again: the pool's threads are parked, not stuck
+            g.step(30, 0)
+
+
 def test_group_checkpoint_restart(lbm, tmp_path):
     """Per-strip checkpoints of a group, restored into a fresh group (lbm_group_refresh_halos), continue bit-exactly."""
     nx, ny = 256, 96
@@ -529,7 +567,7 @@ def test_checkpoint_restart_is_bit_exact(lbm, tmp_path):
     ("rowil-half5-nt", 24, 10, 1, 5),       # force outputs at 10 and 20 end the fused segments: 5+5 | 5+5 | 4
     ("rowil-fuse3-12-nt-xcd", 20, 0, 1, 6), # 4+4+3+3+3+3
     ("rowil-col5-nt", 22, 0, 1, 4),         # 6+6+5+5: the register-column family uses both of its depths too
-    ("fast-rowil-col6", 20, 0, 0, 5),       # 5+5+5+4 and the single last iteration
+    ("planar-col6-alt", 20, 0, 0, 5),       # 5+5+5+4 and the single last iteration
 ])
 def test_a_call_is_split_into_full_rate_launches(lbm, plan, steps, of, trailing, launches):
     """plan_launch: the iterations of a call (between force outputs) are split into the cheapest sequence of the depths the
@@ -550,20 +588,46 @@ def test_a_call_is_split_into_full_rate_launches(lbm, plan, steps, of, trailing,
 
 
 def test_c4_grid_8192x2048_single_gpu(lbm):
-    """BASELINE.json configs[3] grid (8192x2048, Re=200) on ONE GPU (the 8-GPU strip run belongs to the driver):
-    bit-exact populations against the oracle over a bounded window, and decomposition invariance for 8 strips."""
+    """BASELINE.json configs[3] grid (8192x2048, Re=200) on ONE GPU (the 8-GPU strip run belongs to the driver), over the
+    300-iteration window SURVEY §8d C4 asks for (200-500): strict arithmetic on the measured plan — populations bit-identical
+    to the oracle — and the bench's contracted arithmetic on its measured plan within the north-star 1e-10 on rho, u and the
+    momentum-exchange forces; then decomposition invariance for 8 strips."""
     from oracle.oracle import Oracle, make_params
-    nx, ny, steps = 8192, 2048, 12
+    nx, ny, steps = 8192, 2048, 300
     kw = dict(inlet_velocity=0.03255208)
     o = Oracle(make_params(nx, ny, **kw))
     assert o.run(steps) == -1 and o.solid_count() == 32681
+    o_fn = o.f_next.copy()
+    o_m = (o.rho.copy(), o.ux.copy(), o.uy.copy())      # (collide() below moves the oracle's macros on to the next iteration)
+    o.collide()
+    ofx, ofy = o.forces()
     with lbm.Context(nx, ny, **kw) as ctx:
         assert ctx.initialise() == 32681
         ctx.step(steps, 0)
-        assert np.array_equal(ctx.populations("f_next"), o.f_next)
+        assert ctx.first_unstable_step() == -1
+        assert np.array_equal(ctx.populations("f_next"), o_fn)
         w = ctx.macros()
+        er, eu = macro_errors(*w, *o_m)
+        strict_plan = ctx.plan()
+    with lbm.Context(nx, ny, options=dict(arith=1), **kw) as ctx:
+        ctx.initialise()
+        ctx.step(steps, 0)
+        assert ctx.first_unstable_step() == -1
+        cr, cu = macro_errors(*ctx.macros(), *o_m)
+        fx, fy = ctx.forces()
+        cf = max(abs(fx - ofx), abs(fy - ofy)) / abs(ofx)
+        record("c4_8192x2048_f64_300", strict_rho=er, strict_u=eu, contracted_rho=cr, contracted_u=cu, contracted_force=cf,
+               strict_plan=strict_plan, contracted_plan=ctx.plan())
+        print(f"C4 x {steps}: strict rho {er:.2e} u {eu:.2e} (populations bit-equal); contracted rho {cr:.2e} u {cu:.2e} F {cf:.2e} [{ctx.plan()}]")
+        assert er < TOL and eu < TOL and cr < TOL and cu < TOL and cf < TOL, (er, eu, cr, cu, cf)
     o.close()
-    ctxs, _ = _run_strips(lbm, nx, ny, lbm.partition_rows(ny, 8), steps, 0, pairs=True,
+    del o_fn, o_m
+    short = 12
+    with lbm.Context(nx, ny, **kw) as ctx:
+        ctx.initialise()
+        ctx.step(short, 0)
+        w = ctx.macros()
+    ctxs, _ = _run_strips(lbm, nx, ny, lbm.partition_rows(ny, 8), short, 0, pairs=True,
                           plans=["rowil-fuse3-12-nt-xcd"] * 8, **kw)
     parts = [c.macros() for c in ctxs]
     for j in range(3):
@@ -723,26 +787,34 @@ def test_fp32_variant_tracks_fp64(lbm):
             assert np.array_equal(a, b)
 
 
-def test_fp32_tracks_fp64_on_fused_plans_1024x256(lbm):
+def test_fp32_tracks_the_oracle_on_fused_plans_1024x256(lbm):
     """fp32 parity where the fused kernels and the measured plan are in play: BASELINE.json configs[1] grid (1024x256,
-    Re=100), 1000 iterations. The reference has no fp32 path, so the yardstick is the fp64 result of this library
-    (itself pinned to the oracle / the reference). Stated tolerance: 1e-3 relative on rho and on u (L-inf / L-inf, u
-    relative to max|u|); measured on MI355X: see DESIGN.md §4. Every fp32 plan must agree with every other bit for bit."""
+    Re=100), 1000 iterations, against the fp64 ORACLE (the reference has no fp32 path; the oracle is pinned to the reference).
+    Stated tolerance: 1e-3 relative on rho and on u (L-inf / L-inf, u relative to max|u|) — fp32 carries 6e-8 per operation
+    and 1000 iterations of a chaotic wake amplify it; measured on MI355X: DESIGN.md §4 / profiles/r03/parity_measured.jsonl.
+    Every fp32 plan must agree with every other bit for bit, and this library's fp64 path must sit on the oracle."""
+    from oracle.oracle import Oracle, make_params
     nx, ny, steps = 1024, 256, 1000
     kw = dict(inlet_velocity=0.13020833)
+    o = Oracle(make_params(nx, ny, **kw))
+    assert o.run(steps) == -1
+    ref = (o.rho.copy(), o.ux.copy(), o.uy.copy())
+    o.close()
     with lbm.Context(nx, ny, precision="f64", **kw) as ctx:
         ctx.initialise()
         ctx.step(steps, 0)
-        ref = ctx.macros()
+        er, eu = macro_errors(*ctx.macros(), *ref)
+        assert er < TOL and eu < TOL, (er, eu)
     out = {}
-    for plan in ("auto", "rowil-fuse3-12-nt-xcd", "rowil-fuse4-nt-xcd", "planar-slide3-nt", "rowil-slide2-nt", "planar-site"):
+    for plan in ("auto", "rowil-fuse3-12-nt-xcd", "rowil-fuse4-nt-xcd", "planar-slide3-nt", "rowil-slide2-nt", "planar-site",
+                 "rowil-col5-nt", "planar-col6-alt"):
         with lbm.Context(nx, ny, precision="f32", options=PLANS[plan], **kw) as ctx:
             ctx.initialise()
             ctx.step(steps, 0)
             assert ctx.first_unstable_step() == -1
             out[plan] = ctx.macros()
     er, eu = macro_errors(*out["auto"], *ref)
-    print(f"fp32 vs fp64, 1024x256 x {steps}: rho {er:.3e}, u {eu:.3e}")
+    print(f"fp32 vs the fp64 oracle, 1024x256 x {steps}: rho {er:.3e}, u {eu:.3e}")
     assert er < 1e-3 and eu < 1e-3, (er, eu)
     for plan, m in out.items():
         for a, b in zip(out["auto"], m):
@@ -750,16 +822,18 @@ def test_fp32_tracks_fp64_on_fused_plans_1024x256(lbm):
     with lbm.Context(nx, ny, precision="f32", options=PLANS["fast-auto"], **kw) as ctx:      # contracted fp32
         ctx.initialise()
         ctx.step(steps, 0)
-        er, eu = macro_errors(*ctx.macros(), *ref)
-        print(f"fp32 contracted vs fp64: rho {er:.3e}, u {eu:.3e}")
-        assert er < 1e-3 and eu < 1e-3, (er, eu)
+        cr, cu = macro_errors(*ctx.macros(), *ref)
+        print(f"fp32 contracted vs the fp64 oracle: rho {cr:.3e}, u {cu:.3e}")
+        assert cr < 1e-3 and cu < 1e-3, (cr, cu)
+    record("c2_1024x256_f32_vs_oracle_1000", strict_rho=er, strict_u=eu, contracted_rho=cr, contracted_u=cu)
 
 
 def test_c5_grid_16384x4096_fp32_single_gpu(lbm):
     """BASELINE.json configs[4] workload (16384x4096 fp32, Re=200) on ONE GPU (2.4 GB per population buffer; the 8-GPU
     strip run belongs to the driver), with the measured plan. The reference has no fp32 path and a CPU oracle run of 67 M
     cells is out of reach, so at full size the checks are the size-independent properties: geometry (130 721 solid
-    cells), stability over 300 iterations, physical sanity of the fields, run-to-run determinism,
+    cells), stability over 300 iterations, fp32 against this library's fp64 path on the same full-size grid at a
+    stated, measured tolerance, run-to-run determinism,
     plan-to-plan bit-equality (measured plan vs tile kernel vs sliding kernel vs one launch per iteration) and
     decomposition invariance (8 in-process strips with the production exchange choreography == the whole domain)."""
     nx, ny, steps = 16384, 4096, 300
@@ -773,10 +847,25 @@ def test_c5_grid_16384x4096_fp32_single_gpu(lbm):
             return ctx.macros(), ctx.drain_force_log(), ctx.plan(), ctx.kernel_name()
     (rho, ux, uy), log, plan, kernel = run(None)
     print("C5 plan:", plan, "|", kernel)
-    assert np.isfinite(rho).all() and 0.9 < rho.min() and rho.max() < 1.1
-    assert abs(float(ux[ny // 4, nx // 2]) - 0.01627604) < 2e-3 and float(np.abs(uy).max()) < 0.1
-    assert [r[0] for r in log] == [0, 150]
-    for options in (None, PLANS["rowil-fuse3-12-nt-xcd"], PLANS["rowil-fuse4-nt-xcd"], PLANS["planar-slide3-nt"], PLANS["rowil-site-nt"]):
+    assert np.isfinite(rho).all() and [r[0] for r in log] == [0, 150]
+    # the yardstick at full size: this library's fp64 path on the same grid for the same 300 iterations (2 x 4.8 GB; it is
+    # bit-identical to the oracle wherever the oracle reaches: 4096x1024 x 1000, 8192x2048 x 300). Stated tolerance: rho
+    # 2e-5, u 2e-4, forces 1e-4 relative (L-inf / L-inf, u relative to max|u|); measured on MI355X (profiles/r03/
+    # parity_measured.jsonl): rho 5.5e-6, u 3.1e-5, forces 1.7e-5 — the inlet velocity is 0.016, so ONE fp32 rounding of a
+    # population (6e-8 of 0.44) already is 2e-6 of max|u|.
+    with lbm.Context(nx, ny, inlet_velocity=0.01627604, precision="f64") as c64:
+        assert c64.initialise() == 130721
+        c64.step(steps, 150)
+        assert c64.first_unstable_step() == -1
+        m64 = c64.macros()
+        log64 = c64.drain_force_log()
+    er, eu = macro_errors(rho, ux, uy, *m64)
+    ef = max(max(abs(a[1] - b[1]), abs(a[2] - b[2])) / abs(b[1]) for a, b in zip(log, log64))
+    record("c5_16384x4096_f32_vs_hip_f64_300", rho=er, u=eu, force=ef, plan=plan)
+    print(f"C5 fp32 vs fp64 (HIP) x {steps}: rho {er:.3e}, u {eu:.3e}, force {ef:.3e}")
+    del m64
+    assert er < 2e-5 and eu < 2e-4 and ef < 1e-4, (er, eu, ef)
+    for options in (None, PLANS["rowil-fuse3-12-nt-xcd"], PLANS["rowil-half5-nt"], PLANS["planar-slide3-nt"], PLANS["rowil-site-nt"]):
         m2, log2, _, _ = run(options)
         for a, b in zip((rho, ux, uy), m2):
             assert np.array_equal(a, b), options
@@ -809,6 +898,7 @@ def test_full_size_4096x1024_properties(lbm):
         er, eu = macro_errors(rho, ux, uy, o.rho, o.ux, o.uy)
         assert er < TOL and eu < TOL, (er, eu)
         assert np.array_equal(ctx.populations("f_next"), o.f_next)      # bit-identical after 1000 iterations
+        o_m = (o.rho.copy(), o.ux.copy(), o.uy.copy())      # (collide() moves the oracle's macros on to the next iteration)
         o.collide()
         fx, fy = ctx.forces()
         ofx, ofy = o.forces()
@@ -816,6 +906,18 @@ def test_full_size_4096x1024_properties(lbm):
         ctx.step(170, 0)
         assert ctx.first_unstable_step() == -1
         a = ctx.macros()
+    # the bench's own mode: contracted arithmetic on ITS measured plan, the same 1000 iterations against the same oracle run
+    with lbm.Context(nx, ny, options=dict(arith=1), **kw) as ctx:
+        ctx.initialise()
+        ctx.step(steps, 0)
+        assert ctx.first_unstable_step() == -1
+        cr, cu = macro_errors(*ctx.macros(), *o_m)
+        fx, fy = ctx.forces()
+        cf = max(abs(fx - ofx), abs(fy - ofy)) / abs(ofx)
+        record("c3_4096x1024_f64_1000", strict_rho=er, strict_u=eu, contracted_rho=cr, contracted_u=cu, contracted_force=cf,
+               contracted_plan=ctx.plan())
+        print(f"C3 x {steps}: strict rho {er:.2e} u {eu:.2e} (populations bit-equal); contracted rho {cr:.2e} u {cu:.2e} F {cf:.2e} [{ctx.plan()}]")
+        assert cr < TOL and cu < TOL and cf < TOL, (cr, cu, cf)
     o.close()
     with lbm.Context(nx, ny, options=PLANS["rowil-site-nt"], **kw) as ctx:   # a different plan, same bits
         ctx.initialise()
