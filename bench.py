@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--set", action="append", default=[], help="library option key=value (lbm_set_option), e.g. slide=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-arith", action="store_true", help="skip the run in the other arithmetic mode (profiler passes)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the second, longer window (profiler passes)")
     ap.add_argument("--no-f32-variant", action="store_true", help="skip the single-precision variant (BASELINE.json configs[4]) beside the headline")
     args = ap.parse_args()
 
@@ -262,16 +263,17 @@ def main():
     # `sustained`: a second, longer window of the same context (the driver's K may be as short as 20 steps = 4 launches,
     # which a boosting clock flatters by ~5 %): at least 3000 steps / 80 ms
     sus_steps = max(3000, args.steps) if world == 1 else max(1200, args.steps)
-    t1 = time.perf_counter()
-    ctx.step(sus_steps, 0)
-    fence()
-    dt_sus = time.perf_counter() - t1
-    s_ms, s_launches, s_iterations = ctx.last_step_stats()
+    dt_sus = None
+    if not args.no_sustained:
+        t1 = time.perf_counter()
+        ctx.step(sus_steps, 0)
+        fence()
+        dt_sus = time.perf_counter() - t1
     compute_only_ms = None
     if world > 1:
-        tt = torch.tensor([dt, kernel_ms, dt_sus], dtype=torch.float64)
+        tt = torch.tensor([dt, kernel_ms, dt_sus or 0.0], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, kernel_ms, dt_sus = float(tt[0]), float(tt[1]), float(tt[2])
+        dt, kernel_ms, dt_sus = float(tt[0]), float(tt[1]), (float(tt[2]) if dt_sus else None)
     bad = ctx.first_unstable_step()
     if bad != -1:
         sys.exit(f"simulation unstable at timestep {bad}: result invalid")
@@ -336,11 +338,12 @@ def main():
                        "kernel": kernel, "plan": ctx.plan(), "build_id": lbm.build_id(),
                        "runtime": {"rccl": versions["rccl"], "hip_runtime": versions["hip_runtime"], "hip_driver": versions["hip_driver"],
                                    "torch_loaded": torch is not None}},
-            "sustained": {"value": round(cells * sus_steps / dt_sus / 1e6, 1), "unit": "MLUPS", "steps": sus_steps,
-                          "ms_per_step": round(dt_sus / sus_steps * 1e3, 5),
-                          "note": "a second, longer window of the same context, same fences; `value` above is the contract's K-step window"},
             "roofline": roof,
         }
+        if dt_sus:
+            line["sustained"] = {"value": round(cells * sus_steps / dt_sus / 1e6, 1), "unit": "MLUPS", "steps": sus_steps,
+                                 "ms_per_step": round(dt_sus / sus_steps * 1e3, 5),
+                                 "note": "a second, longer window of the same context, same fences; `value` above is the contract's K-step window"}
         if world > 1:
             line["strips"] = {"nranks": world, "schedule": ctx.strip_schedule(),
                               "ms_per_step_compute_only": round(compute_only_ms, 5),
