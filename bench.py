@@ -129,7 +129,7 @@ def measured_traffic(nx, local_ny, precision, kernel, layout=""):
 
 
 def plan_depth_of(kernel):
-    m = re.match(r"k_step(\d)_tile|k_step_slide<\w+,(\d)|k_stepd_tile<\w+,\d+,\d+,(\d)|k_stepc_col<\w+,\d+,\d+,(\d)", kernel)
+    m = re.match(r"k_step(\d)_tile|k_stepd_tile<\w+,\d+,\d+,(\d)|k_stepc_col<\w+,\d+,\d+,(\d)", kernel)
     return int(next(g for g in m.groups() if g)) if m else 1
 
 
@@ -192,7 +192,7 @@ def main():
                          "permits; rho/u within 1e-10 of the reference, tests), strict = IEEE op by op (bit-identical to the CPU oracle)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong: the named grid cut into N strips (BASELINE metric); weak: ny rows PER GPU")
-    ap.add_argument("--set", action="append", default=[], help="library option key=value (lbm_set_option), e.g. slide=1")
+    ap.add_argument("--set", action="append", default=[], help="library option key=value (lbm_set_option), e.g. deep=7")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-arith", action="store_true", help="skip the run in the other arithmetic mode (profiler passes)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the second, longer window (profiler passes)")

@@ -1,0 +1,25 @@
+// csrc/lbm_col.hip — the translation unit of k_stepc_col (lbm_kernel_col.hpp): its sixteen instantiations (five / six
+// iterations x store policy x arithmetic x element type) and the launcher lbm_hip.hip calls (lbm_col_api.hpp).
+#include "lbm_kernel_col.hpp"
+#include "lbm_col_api.hpp"
+
+namespace lbmk {
+
+template <typename T>
+void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool contracted, hipStream_t s) {
+#define LBM_KC(D_) do { \
+        constexpr int OW_ = col_tile_w(D_), OH_ = col_tile_h(D_); \
+        const int nb_ = ((a.nx + OW_ - 1) / OW_) * ((a.y_cnt + OH_ - 1) / OH_ + (a.y_cnt2 + OH_ - 1) / OH_); \
+        const dim3 gridc((unsigned)((nb_ + 7) / 8 * 8)), blockc(COL_NW * 64); \
+        if (nt) { if (contracted) hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, true, AR_CONTRACTED>), gridc, blockc, 0, s, a, e); \
+                  else hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, true, AR_STRICT>), gridc, blockc, 0, s, a, e); } \
+        else { if (contracted) hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, false, AR_CONTRACTED>), gridc, blockc, 0, s, a, e); \
+               else hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, false, AR_STRICT>), gridc, blockc, 0, s, a, e); } } while (0)
+    if (depth == 5) LBM_KC(5); else LBM_KC(6);
+#undef LBM_KC
+}
+
+template void launch_col<double>(const KArgs<double>&, const K2Extra<double>&, int, bool, bool, hipStream_t);
+template void launch_col<float>(const KArgs<float>&, const K2Extra<float>&, int, bool, bool, hipStream_t);
+
+}  // namespace lbmk

@@ -1,7 +1,7 @@
 // csrc/lbm_hip.hip — host side of liblbm_hip.so: the C-ABI of include/lbm_hip.h over the gfx950 kernels in
 // lbm_kernels.hpp. Plain HIP runtime + RCCL; no torch types, no CPU fallback.
 #include "lbm_kernels.hpp"
-#include "lbm_kernel_col.hpp"
+#include "lbm_col_api.hpp"
 #include "../../include/lbm_hip.h"
 
 #include <rccl/rccl.h>
@@ -155,10 +155,9 @@ struct lbm_ctx {
     int xcd = 0;         // fused kernels: remap blocks so that each XCD walks a contiguous run of tiles
     bool deep_now = false;   // the launch being issued is the plan's deep launch (set by plan_launch)
     int deep = 0;        // 1..3: k_stepd_tile shape (6/7/8 iterations per launch on an LDS-filling tile); whole-domain launches only
-    int slide = 0;       // fused launches use the sliding-window kernel k_step_slide (column blocks marching in y)
     int arith = 0;       // collision arithmetic: 0 strict IEEE op-by-op (bit-identical to the oracle), 1 contracted (FMA +
                          // one reciprocal, as the reference's -ffast-math -mfma build permits); see lbm_kernels.hpp Arith
-    int num_cus = 256;   // compute units of the device (k_step_slide sizes its segments so that all blocks are resident)
+    int num_cus = 256;   // compute units of the device (what counts as a small grid: one round of blocks)
     int loopback = 0;    // TEST ONLY: the strip is its own north and south neighbour (exercises the overlap choreography):
                          // 1 = device copies, 2 = RCCL send/recv to self on a one-rank communicator
     int deep_halo = 1;       // strips: one exchange of GR rows per TWO launches (the first launch of a pair is extended)
@@ -168,6 +167,10 @@ struct lbm_ctx {
     bool restored = false;   // state came from lbm_load_state: no previous-iteration buffer until the next step
     int tune = 1;        // lbm_initialise times the candidate plans on this device and keeps the fastest
     char plan_desc[160] = "";
+    double depth_rel[4] = {2.8, 1.6, 1.12, 1.08};   // cost per iteration of a 1- / 2- / 3- / 4-iteration launch relative to the plan's deep
+                                                    // launch (plan_launch's tail split); measured by choose_plan on a single domain,
+                                                    // these defaults — 4096x1024 fp64, round 2 — elsewhere (strips: every rank must split alike)
+    bool depth_rel_measured = false;
     int timing = 0;
     int overlap = 1;
     bool overlap_pinned = false, deep_pinned = false;   // set through lbm_set_option: the strip tuner leaves them alone
@@ -250,165 +253,93 @@ inline void configure_layout(lbm_ctx* c, int layout) {
 }
 inline size_t buffer_bytes(const lbm_ctx* c) { return c->total * c->esize + 256; }  // +slack: displaced vector load
 
-// Launch one step-family kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt).
+// Launch one step-family kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt). Instantiated: MODE_STEP in both store
+// policies and both arithmetic modes, MODE_COLLIDE_ONLY in both arithmetic modes, MODE_STREAM_ONLY once (no collision in it).
 template <typename T, int MODE>
 void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
     constexpr int V = vec_width<T>();
     const bool nt = (MODE == MODE_STEP) && c->use_nt;
-    const bool fast = (MODE != MODE_STREAM_ONLY) && c->arith == AR_CONTRACTED;   // (the stream-only snapshot has no collision)
-    constexpr int AF = (MODE == MODE_STREAM_ONLY) ? AR_STRICT : AR_CONTRACTED;
-    if (use_vec(c)) {
-        dim3 grid((c->nx / V + 255) / 256, a.y_cnt + a.y_cnt2), block(256);
-        if (fast) {
-            if (nt) hipLaunchKernelGGL((k_step_vec<T, V, MODE, true, AF>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((k_step_vec<T, V, MODE, false, AF>), grid, block, 0, s, a);
-        } else {
-            if (nt) hipLaunchKernelGGL((k_step_vec<T, V, MODE, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((k_step_vec<T, V, MODE, false>), grid, block, 0, s, a);
-        }
+    const bool fast = (MODE != MODE_STREAM_ONLY) && c->arith == AR_CONTRACTED;
+    const bool vec = use_vec(c);
+    const dim3 grid(vec ? (c->nx / V + 255) / 256 : (c->nx + 255) / 256, a.y_cnt + a.y_cnt2), block(256);
+#define LBM_K1(NT_, AR_) do { if (vec) hipLaunchKernelGGL((k_step_vec<T, V, MODE, NT_, AR_>), grid, block, 0, s, a); \
+                              else hipLaunchKernelGGL((k_step_site<T, MODE, NT_, AR_>), grid, block, 0, s, a); } while (0)
+    if constexpr (MODE == MODE_STEP) {
+        if (fast) { if (nt) LBM_K1(true, AR_CONTRACTED); else LBM_K1(false, AR_CONTRACTED); }
+        else { if (nt) LBM_K1(true, AR_STRICT); else LBM_K1(false, AR_STRICT); }
+    } else if constexpr (MODE == MODE_COLLIDE_ONLY) {
+        if (fast) LBM_K1(false, AR_CONTRACTED); else LBM_K1(false, AR_STRICT);
     } else {
-        dim3 grid((c->nx + 255) / 256, a.y_cnt + a.y_cnt2), block(256);
-        if (fast) {
-            if (nt) hipLaunchKernelGGL((k_step_site<T, MODE, true, AF>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((k_step_site<T, MODE, false, AF>), grid, block, 0, s, a);
-        } else {
-            if (nt) hipLaunchKernelGGL((k_step_site<T, MODE, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((k_step_site<T, MODE, false>), grid, block, 0, s, a);
-        }
+        LBM_K1(false, AR_STRICT);
     }
+#undef LBM_K1
 }
 
-// "deep" plans: shape id -> iterations per launch and tile. 1..5: LDS-image tiles (k_stepd_tile); 6..8: the register-
-// resident column kernel (k_stepc_col, R = 4 rows per thread x 8 waves = a 64 x 32 region per block, two blocks per CU):
-// 6 / 7 = the five- / six-iteration members of that family (a plan of either uses both depths for what a segment leaves
-// over; seven and eight iterations were measured at 4096x1024 fp64 — 160.6 / 154.3 GLUPS against 161.7 — and are not built).
-constexpr int COL_R = 4, COL_NW = 8;
+// "deep" plans: shape id -> iterations per launch and tile. 1..3: LDS-image tiles (k_stepd_tile: six / seven iterations on
+// 64x16 tiles, eight on 32x32; what a grid of a single round of blocks picks); 6 / 7: the register-resident column kernel
+// (k_stepc_col, R = 4 rows per thread x 8 waves = a 64 x 32 region per block, two blocks per CU) with five / six iterations —
+// a plan of either uses both depths for what a segment leaves over (seven and eight iterations were measured at 4096x1024
+// fp64 — 160.6 / 154.3 GLUPS against 161.7 — and are not built). Ids 4 / 5 were round 2's 32x16 LDS tiles: retired.
 inline bool deep_is_col(int id) { return id == 6 || id == 7; }
+inline bool deep_valid(int id) { return id == 0 || (id >= 1 && id <= 3) || deep_is_col(id); }
 inline int deep_depth(int id) {
-    static const int d[8] = {0, 6, 7, 8, 5, 6, 5, 6};
+    static const int d[8] = {0, 6, 7, 8, 0, 0, 5, 6};
     return id >= 0 && id <= 7 ? d[id] : 0;
 }
-// the other depth of a two-member family (32x16 tiles: ids 4/5, column kernel: ids 6/7), 0 if the shape stands alone
-inline int deep_alt_depth(int id) { return (id == 4 || id == 6) ? 6 : (id == 5 || id == 7) ? 5 : 0; }
+// the other depth of the two-member column family (ids 6/7), 0 if the shape stands alone
+inline int deep_alt_depth(int id) { return id == 6 ? 6 : id == 7 ? 5 : 0; }
 // rows of one band of tiles of a launch of `depth` iterations (the edge bands of a strip are one band each)
 inline int deep_rows(int id, int depth) {
-    if (deep_is_col(id)) return COL_R * COL_NW - 2 * (depth - 1);
+    if (deep_is_col(id)) return col_tile_h(depth);
     return id == 3 ? 32 : 16;
 }
 inline const char* deep_tile(int id) {
-    static const char* t[6] = {"", "64,16", "64,16", "32,32", "32,16", "32,16"};
-    return id >= 0 && id <= 5 ? t[id] : "";
+    static const char* t[4] = {"", "64,16", "64,16", "32,32"};
+    return id >= 0 && id <= 3 ? t[id] : "";
 }
 
-// A fused kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt): iterations a.t .. a.t + depth - 1 (depth 2 or 3).
+// A fused kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt): iterations a.t .. a.t + depth - 1 (depth 2..8).
 template <typename T>
 void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s) {
     K2Extra<T> e;
     e.feq_in = static_cast<const T*>(c->d_feq);
     e.small = ((c->total + (size_t)c->pitch) * c->esize + 1024 < (size_t(1) << 32)) ? 1 : 0;   // 32-bit byte offsets (+ one row of slack)
-    if (c->slide) {
-        // Column blocks of 64 cells marching up segments of seg_h rows in bands of SB rows. Segments are sized so that
-        // every block of the launch is resident at once (two blocks per CU): one wave of blocks, no tail.
-        constexpr int SB = 6;
-        SlideArgs sa;
-        sa.ncol = (c->nx + 63) / 64;
-        const int rows = a.y_cnt + a.y_cnt2;
-        const int want = std::max(1, 2 * c->num_cus / sa.ncol);
-        sa.seg_h = std::max(round_up((rows + want - 1) / want, SB), 2 * SB);
-        sa.nseg1 = (a.y_cnt + sa.seg_h - 1) / sa.seg_h;
-        sa.nseg2 = (a.y_cnt2 + sa.seg_h - 1) / sa.seg_h;
-        dim3 grid(sa.ncol * (sa.nseg1 + sa.nseg2)), block((SB + 1) * 64);
-#define LBM_KS(D_, NT_, AR_) hipLaunchKernelGGL((k_step_slide<T, D_, SB, NT_, AR_>), grid, block, 0, s, a, e, sa)
-        const int sel = (depth == 3 ? 4 : 0) + (c->use_nt ? 2 : 0) + (c->arith == AR_CONTRACTED ? 1 : 0);
-        switch (sel) {
-            case 0: LBM_KS(2, false, AR_STRICT); break;
-            case 1: LBM_KS(2, false, AR_CONTRACTED); break;
-            case 2: LBM_KS(2, true, AR_STRICT); break;
-            case 3: LBM_KS(2, true, AR_CONTRACTED); break;
-            case 4: LBM_KS(3, false, AR_STRICT); break;
-            case 5: LBM_KS(3, false, AR_CONTRACTED); break;
-            case 6: LBM_KS(3, true, AR_STRICT); break;
-            default: LBM_KS(3, true, AR_CONTRACTED); break;
-        }
-#undef LBM_KS
+    e.xcd = c->xcd;
+    e.nt = c->use_nt;
+    const bool fast = c->arith == AR_CONTRACTED;
+    if (c->deep_now && deep_is_col(c->deep)) {    // D iterations with the lattice in registers (k_stepc_col, lbm_col.hip)
+        launch_col<T>(a, e, depth, c->use_nt != 0, fast, s);
         return;
     }
-    if (c->deep_now && deep_is_col(c->deep)) {    // D iterations with the lattice in registers (k_stepc_col)
-        const bool fastd = c->arith == AR_CONTRACTED;
-#define LBM_KC(D_) do { \
-        constexpr int OW_ = 64 - 2 * (D_ - 1), OH_ = COL_R * COL_NW - 2 * (D_ - 1); \
-        const int nb_ = ((c->nx + OW_ - 1) / OW_) * ((a.y_cnt + OH_ - 1) / OH_ + (a.y_cnt2 + OH_ - 1) / OH_); \
-        const dim3 gridc((unsigned)round_up(nb_, 8)), blockc(COL_NW * 64); \
-        if (c->use_nt) { if (fastd) hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, true, AR_CONTRACTED>), gridc, blockc, 0, s, a, e); \
-                         else hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, true, AR_STRICT>), gridc, blockc, 0, s, a, e); } \
-        else { if (fastd) hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, false, AR_CONTRACTED>), gridc, blockc, 0, s, a, e); \
-               else hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, false, AR_STRICT>), gridc, blockc, 0, s, a, e); } } while (0)
-        if (depth == 5) LBM_KC(5); else LBM_KC(6);
-#undef LBM_KC
-        return;
-    }
-    if (c->deep_now) {    // D iterations on a deep tile (k_stepd_tile; whole-domain launches)
-        const int shape = c->deep >= 4 ? (depth == 5 ? 4 : 5) : c->deep;   // (the 32x16 family: kernel by depth)
-        const bool fastd = c->arith == AR_CONTRACTED;
+    if (c->deep_now) {    // D iterations on a deep LDS tile (k_stepd_tile; whole-domain launches of small grids)
 #define LBM_KD(TX_, TY_, D_) do { \
         dim3 gridd((c->nx + TX_ - 1) / TX_, (a.y_cnt + TY_ - 1) / TY_ + (a.y_cnt2 + TY_ - 1) / TY_); \
-        if (c->use_nt) { if (fastd) hipLaunchKernelGGL((k_stepd_tile<T, TX_, TY_, D_, true, true, AR_CONTRACTED>), gridd, dim3(TX_ * TY_), 0, s, a, e); \
-                         else hipLaunchKernelGGL((k_stepd_tile<T, TX_, TY_, D_, true, true, AR_STRICT>), gridd, dim3(TX_ * TY_), 0, s, a, e); } \
-        else { if (fastd) hipLaunchKernelGGL((k_stepd_tile<T, TX_, TY_, D_, false, true, AR_CONTRACTED>), gridd, dim3(TX_ * TY_), 0, s, a, e); \
-               else hipLaunchKernelGGL((k_stepd_tile<T, TX_, TY_, D_, false, true, AR_STRICT>), gridd, dim3(TX_ * TY_), 0, s, a, e); } } while (0)
-        switch (shape) {
+        if (fast) hipLaunchKernelGGL((k_stepd_tile<T, TX_, TY_, D_, AR_CONTRACTED>), gridd, dim3(TX_ * TY_), 0, s, a, e); \
+        else hipLaunchKernelGGL((k_stepd_tile<T, TX_, TY_, D_, AR_STRICT>), gridd, dim3(TX_ * TY_), 0, s, a, e); } while (0)
+        switch (c->deep) {
             case 1: LBM_KD(64, 16, 6); break;
             case 2: LBM_KD(64, 16, 7); break;
-            case 3: LBM_KD(32, 32, 8); break;
-            case 4: LBM_KD(32, 16, 5); break;       // 512-thread blocks: two per CU in fp64
-            default: LBM_KD(32, 16, 6); break;
+            default: LBM_KD(32, 32, 8); break;
         }
 #undef LBM_KD
         return;
     }
     const int ty = c->pair_ty;
     dim3 grid((c->nx + 63) / 64, (a.y_cnt + ty - 1) / ty + (a.y_cnt2 + ty - 1) / ty);
-#define LBM_K2(TY_, NTH_, NT_, X_) do { if (fast) hipLaunchKernelGGL((k_step2_tile<T, TY_, NTH_, NT_, X_, AR_CONTRACTED>), grid, dim3(NTH_), 0, s, a, e); \
-                                         else hipLaunchKernelGGL((k_step2_tile<T, TY_, NTH_, NT_, X_, AR_STRICT>), grid, dim3(NTH_), 0, s, a, e); } while (0)
-#define LBM_K3(TY_, NTH_, NT_, X_) do { if (fast) hipLaunchKernelGGL((k_step3_tile<T, TY_, NTH_, NT_, X_, AR_CONTRACTED>), grid, dim3(NTH_), 0, s, a, e); \
-                                         else hipLaunchKernelGGL((k_step3_tile<T, TY_, NTH_, NT_, X_, AR_STRICT>), grid, dim3(NTH_), 0, s, a, e); } while (0)
-    const bool fast = c->arith == AR_CONTRACTED;
-    const int sel = (ty == 12 ? 4 : 0) + (c->use_nt ? 2 : 0) + (c->xcd ? 1 : 0);
-    if (depth == 4) {   // four iterations: 64x8 tiles only (LDS), nt stores and XCD walk as in the plan
+#define LBM_KT(K_, TY_, NTH_, G_) do { if (fast) hipLaunchKernelGGL((K_<T, TY_, NTH_, AR_CONTRACTED>), G_, dim3(NTH_), 0, s, a, e); \
+                                       else hipLaunchKernelGGL((K_<T, TY_, NTH_, AR_STRICT>), G_, dim3(NTH_), 0, s, a, e); } while (0)
+    if (depth == 4) {   // four iterations: 64x8 tiles only (LDS)
         dim3 grid4((c->nx + 63) / 64, (a.y_cnt + 7) / 8 + (a.y_cnt2 + 7) / 8);
         // fp64: 70.5 KB of LDS per block = two blocks per CU, so 1024 threads fill the 32 wave slots; fp32 (35 KB) fills them
         // with four 512-thread blocks (measured: 1024 threads -14 % in fp32, +3 % in fp64)
         constexpr int N4 = sizeof(T) == 8 ? 1024 : 512;
-#define LBM_K4(NT_, X_) do { if (fast) hipLaunchKernelGGL((k_step4_tile<T, 8, N4, NT_, X_, AR_CONTRACTED>), grid4, dim3(N4), 0, s, a, e); \
-                             else hipLaunchKernelGGL((k_step4_tile<T, 8, N4, NT_, X_, AR_STRICT>), grid4, dim3(N4), 0, s, a, e); } while (0)
-        if (c->use_nt) { if (c->xcd) LBM_K4(true, true); else LBM_K4(true, false); }
-        else { if (c->xcd) LBM_K4(false, true); else LBM_K4(false, false); }
-#undef LBM_K4
+        LBM_KT(k_step4_tile, 8, N4, grid4);
     } else if (depth == 3) {
-        switch (sel) {
-            case 0: LBM_K3(8, 512, false, false); break;
-            case 1: LBM_K3(8, 512, false, true); break;
-            case 2: LBM_K3(8, 512, true, false); break;
-            case 3: LBM_K3(8, 512, true, true); break;
-            case 4: LBM_K3(12, 1024, false, false); break;
-            case 5: LBM_K3(12, 1024, false, true); break;
-            case 6: LBM_K3(12, 1024, true, false); break;
-            default: LBM_K3(12, 1024, true, true); break;
-        }
+        if (ty == 12) LBM_KT(k_step3_tile, 12, 1024, grid); else LBM_KT(k_step3_tile, 8, 512, grid);
     } else {
-        switch (sel) {
-            case 0: LBM_K2(8, 512, false, false); break;
-            case 1: LBM_K2(8, 512, false, true); break;
-            case 2: LBM_K2(8, 512, true, false); break;
-            case 3: LBM_K2(8, 512, true, true); break;
-            case 4: LBM_K2(12, 768, false, false); break;
-            case 5: LBM_K2(12, 768, false, true); break;
-            case 6: LBM_K2(12, 768, true, false); break;
-            default: LBM_K2(12, 768, true, true); break;
-        }
+        if (ty == 12) LBM_KT(k_step2_tile, 12, 768, grid); else LBM_KT(k_step2_tile, 8, 512, grid);
     }
-#undef LBM_K2
-#undef LBM_K3
+#undef LBM_KT
 }
 inline bool pair_possible(const lbm_ctx*) { return true; }   // partial tiles cover any nx
 template <typename T>
@@ -617,14 +548,14 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
     c->deep_now = false;
     if (c->fuse > 1) {
         const int room = remaining - (c->trailing_pair ? 0 : 1);       // iterations a fused launch may take now
-        int dmax = std::min(c->fuse, (any_face || c->slide) ? 3 : 4);  // (four: k_step4_tile, no faces)
+        int dmax = std::min(c->fuse, any_face ? 3 : 4);  // (four: k_step4_tile, no faces)
         // a deep plan: D iterations while D fit, then the four-/three-/two-iteration tile kernels for what is left
         // (a strip with faces: its ghost rows go GR deep and are refreshed after every launch, so a deep launch of up to GR
         // iterations works there too — the 32x16 and 64x16 shapes with five / six iterations, not the seven / eight ones)
         // Whether the faces are EXCHANGED in this call (strip_logic) or not (the plan probe), a context whose rows end at an
         // internal face has GR rows beyond them and no more: the seven- / eight-iteration shapes would read past the frame.
         const bool phys_face = face_south(c) || face_north(c);
-        const int deep = (!c->slide && c->deep && (!phys_face || deep_depth(c->deep) <= GR)) ? deep_depth(c->deep) : 0;
+        const int deep = (c->deep && (!phys_face || deep_depth(c->deep) <= GR)) ? deep_depth(c->deep) : 0;
         if (deep) {
             // `seg` iterations may be fused from here: up to the next force-output iteration (its post-collision state
             // must exist in memory) and the end of the call. A long segment takes the plan's depth; near its end the
@@ -636,7 +567,7 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
             dmax = std::min(any_face ? 3 : 4, std::min(deep, alt ? alt : deep) - 1);
             if (seg >= 4 * deep) depth = deep;
             else if (seg >= 2) {
-                static const double per_it[4] = {2.8, 1.6, 1.12, 1.08};          // depth 1..4 relative to the deep kernel
+                const double* per_it = c->depth_rel;                             // depth 1..4 relative to the deep kernel
                 double best[64];
                 int first[64];
                 best[0] = 0.0; first[0] = 0;
@@ -658,7 +589,7 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
         // A three-iteration plan leaves a one- or two-iteration launch at the end of a call whose length is not a
         // multiple of three, which runs at half the rate. Where the four-iteration kernel is usable, one (remainder 1)
         // or two (remainder 2) four-iteration launches absorb it: 20 = 4 + 4 + 3 + 3 + 3 + 3.
-        if (c->fuse == 3 && dmax == 3 && !any_face && !c->slide && of <= 0 && (room % 3 == 1 ? room >= 4 : (room % 3 == 2 && room >= 8)))
+        if (c->fuse == 3 && dmax == 3 && !any_face && of <= 0 && (room % 3 == 1 ? room >= 4 : (room % 3 == 2 && room >= 8)))
             dmax = 4;
         for (int d = dmax; d >= 2 && depth == 1; --d) {
             if (room < d) continue;
@@ -693,7 +624,7 @@ int issue_before(lbm_ctx* c, const Launch& L) {
         HIPCHK(hipGetLastError());
         return LBM_OK;
     }
-    const int E = c->deep_now ? deep_rows(c->deep, L.depth) : L.depth > 1 ? (c->slide ? GR : c->pair_ty) : GR;   // one tile band / one band of the sliding kernel
+    const int E = c->deep_now ? deep_rows(c->deep, L.depth) : L.depth > 1 ? c->pair_ty : GR;   // one tile band
     if (L.kind == KIND_EXTENDED) {   // all rows of the strip PLUS the EXT ghost rows next to each internal face
         const int es = face_south(c) ? EXT : 0, en = face_north(c) ? EXT : 0;
         int e0 = face_south(c) ? E : 0, e1 = face_north(c) ? E : 0;
@@ -856,17 +787,13 @@ inline int alloc_buffers(lbm_ctx* c) {
 // 4096x1024 fp64 depending on the allocation). All candidates compute bit-identical results, so lbm_initialise
 // times each one on the real buffers (12 warm-up iterations, then the faster of two 36-iteration windows) and keeps the fastest together
 // with the very allocation it was measured on.
-struct Plan { int layout, variant, nt, alternate, fuse, ty, xcd; const char* name; int slide = 0; int deep = 0; };
+struct Plan { int layout, variant, nt, alternate, fuse, ty, xcd; const char* name; int deep = 0; };
 
 inline void apply_plan(lbm_ctx* c, const Plan& pl) {
     configure_layout(c, pl.layout);
     c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate; c->fuse = pl.fuse > 0 ? pl.fuse : 1; c->xcd = pl.xcd;
     if (pl.ty) c->pair_ty = pl.ty;
-    c->slide = pl.slide;
     c->deep = pl.deep;
-    if (c->slide && c->total * c->esize >= (size_t(1) << 32)) {   // k_step_slide addresses a buffer with 32-bit byte offsets
-        c->slide = 0;
-    }
 }
 
 template <typename T>
@@ -905,7 +832,7 @@ template <typename T>
 int choose_plan(lbm_ctx* c) {
     const bool strips = (c->comm && c->nranks > 1) || c->group_n > 1 || c->loopback;
     const Plan fixed = {(strips || c->loopback) ? 1 : c->layout, c->variant, c->use_nt, c->alternate, c->fuse, c->pair_ty, c->xcd,
-                        "fixed by options", c->slide, c->deep};
+                        "fixed by options", c->deep};
     std::vector<Plan> cand;
     const bool vec_ok = (c->nx % vec_width<T>() == 0), p2 = pair_possible(c);
     // "small": 1024-cell tiles make at most two rounds of one block per CU (fp32: two blocks per CU)
@@ -922,7 +849,7 @@ int choose_plan(lbm_ctx* c) {
     const bool strip_deep = strips && c->p.ny / nstrips >= 64;
     if (!c->tune) cand.push_back(fixed);
     else if (!can_tune) {
-        if (strip_deep) cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers (default, not measured)", 0, 7});
+        if (strip_deep) cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers (default, not measured)", 7});
         else if (strips) cand.push_back({1, 1, 1, 0, p2 ? 3 : 1, 12, 1, "row-interleaved (default, not measured)"});
         else cand.push_back({0, vec_ok ? 0 : 1, 1, 0, p2 ? 3 : 1, 12, 0, "planar (default, not measured)"});
     } else {
@@ -932,28 +859,27 @@ int choose_plan(lbm_ctx* c) {
         // a strip has 64 rows or more, else 3 iterations on 64x12 tiles; only rank-local choices are measured.
         if (strip_deep) {
             // tall strips: six (five) iterations per launch on 64x32 regions held in registers, one exchange of the GR rows after every launch
-            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-store/xcd", 0, 7});
-            cand.push_back({1, 1, 0, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/xcd", 0, 7});
+            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-store/xcd", 7});
+            cand.push_back({1, 1, 0, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/xcd", 7});
         } else if (strips) {
             const int f = p2 ? 3 : 1;
-            if (p2) cand.push_back({1, 1, 1, 0, f, 12, 1, "row-interleaved/3-step sliding 64-column/nt-store", 1});
-            if (p2) cand.push_back({1, 1, 0, 0, f, 12, 1, "row-interleaved/3-step sliding 64-column", 1});
             cand.push_back({1, 1, 1, 0, f, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
             cand.push_back({1, 1, 1, 0, f, 12, 0, "row-interleaved/3-step 64x12/nt-store"});
             cand.push_back({1, 1, 0, 1, f, 12, 1, "row-interleaved/3-step 64x12/alternate/xcd"});
         } else {
             if (p2) cand.push_back({1, 1, 1, 0, 4, 8, 1, "row-interleaved/4-step 64x8/nt-store/xcd"});
-            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-store/xcd", 0, 7});   // k_stepc_col
-            cand.push_back({1, 1, 1, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/nt-store/xcd", 0, 6});
-            cand.push_back({1, 1, 1, 0, 5, 12, 1, "row-interleaved/5-step 32x16/nt-store/xcd", 0, 4});   // two 512-thread blocks per CU (fp64)
-            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 32x16/nt-store/xcd", 0, 5});
-            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x16/nt-store/xcd", 0, 1});
+            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-store/xcd", 7});   // k_stepc_col
+            cand.push_back({1, 1, 1, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/nt-store/xcd", 6});
+            // (non-temporal stores pay where most of the lattice fits the 256 MiB Infinity Cache — 4096x1024 fp64: +1 % — and
+            // cost 3-12 % on the large grids: 8192x2048 fp64 168 -> 173 GLUPS, 16384x4096 fp32 259 -> 290 without them)
+            cand.push_back({1, 1, 0, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/xcd", 7});
+            cand.push_back({1, 1, 0, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/xcd", 6});
+            cand.push_back({1, 1, 0, 1, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/alternate/xcd", 7});
+            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x16/nt-store/xcd", 1});
             if (small_grid && !face_south(c) && !face_north(c)) {   // one round of LDS-filling tiles: a launch's load and store phases are paid once per 7-8 iterations
-                cand.push_back({1, 1, 1, 0, 7, 12, 1, "row-interleaved/7-step 64x16/nt-store/xcd", 0, 2});
-                cand.push_back({1, 1, 1, 0, 8, 12, 1, "row-interleaved/8-step 32x32/nt-store/xcd", 0, 3});
+                cand.push_back({1, 1, 1, 0, 7, 12, 1, "row-interleaved/7-step 64x16/nt-store/xcd", 2});
+                cand.push_back({1, 1, 1, 0, 8, 12, 1, "row-interleaved/8-step 32x32/nt-store/xcd", 3});
             }
-            if (p2) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step sliding 64-column/nt-store", 1});
-            if (p2) cand.push_back({1, 1, 0, 0, 3, 12, 1, "row-interleaved/3-step sliding 64-column", 1});
             if (p2) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
             if (p2) cand.push_back({1, 1, 1, 0, 3, 8, 1, "row-interleaved/3-step 64x8/nt-store/xcd"});
             if (p2) cand.push_back({1, 1, 1, 0, 2, 12, 1, "row-interleaved/2-step 64x12/nt-store/xcd"});
@@ -963,10 +889,7 @@ int choose_plan(lbm_ctx* c) {
         }
         if (!strips) {
             if (p2) cand.push_back({0, 0, 1, 0, 4, 8, 1, "planar/4-step 64x8/nt-store/xcd"});
-            cand.push_back({0, 0, 1, 0, 6, 12, 1, "planar/6-step 64x32 in registers/nt-store/xcd", 0, 7});
-            cand.push_back({0, 0, 1, 0, 5, 12, 1, "planar/5-step 32x16/nt-store/xcd", 0, 4});
-            if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 1, "planar/3-step sliding 64-column/nt-store", 1});
-            if (p2) cand.push_back({0, 0, 0, 0, 3, 12, 1, "planar/3-step sliding 64-column", 1});
+            cand.push_back({0, 0, 1, 0, 6, 12, 1, "planar/6-step 64x32 in registers/nt-store/xcd", 7});
             if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 1, "planar/3-step 64x12/nt-store/xcd"});
             if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 0, "planar/3-step 64x12/nt-store"});
             if (p2) cand.push_back({0, 0, 1, 0, 2, 12, 0, "planar/2-step 64x12/nt-store"});
@@ -1022,6 +945,25 @@ int choose_plan(lbm_ctx* c) {
     if (cand.size() > 1) snprintf(c->plan_desc, sizeof(c->plan_desc), "%s (fastest of %zu measured, %.1f us/iteration)",
                                   cand[best].name, cand.size(), best_ms * 1e3f);
     else snprintf(c->plan_desc, sizeof(c->plan_desc), "%s", cand[best].name);
+    if (cand.size() > 1 && c->deep && !strips && best_ms > 0.f) {
+        // What the shallow launches cost on THIS grid and allocation, for plan_launch's split of a segment's last iterations
+        // (a single domain only: the strips of a run must all split alike, so they keep the fixed table).
+        const Plan keep = cand[best];
+        for (int d = 1; d <= 4; ++d) {
+            Plan q = keep;
+            q.deep = 0; q.fuse = d; q.ty = d == 4 ? 8 : 12;
+            apply_plan(c, q);
+            configure_layout(c, keep.layout);
+            float ms = 0.f;
+            int rc = time_plan<T>(c, &ms);
+            if (rc) return rc;
+            c->depth_rel[d - 1] = std::max(1.0, (double)ms / (double)best_ms);
+        }
+        c->depth_rel_measured = true;
+        apply_plan(c, keep);
+        c->launches_total = 0;
+        c->last_was_pair = false;
+    }
     return LBM_OK;
 }
 
@@ -1883,7 +1825,7 @@ int lbm_load_state(lbm_ctx* c, const char* path) {
 int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     if (!c || !key) return fail(LBM_ERR_ARG, "null argument");
     const std::string k(key);
-    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune" || k == "pair" || k == "fuse" || k == "pair_ty" || k == "loopback" || k == "slide" || k == "deep" || k == "arith"))
+    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune" || k == "pair" || k == "fuse" || k == "pair_ty" || k == "loopback" || k == "deep" || k == "arith"))
         return fail(LBM_ERR_ARG, "option %s must be set before lbm_initialise", key);
     if (k == "variant") c->variant = (int)value;
     else if (k == "timing") c->timing = (int)value;
@@ -1892,16 +1834,14 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "nt") c->use_nt = (int)value ? 1 : 0;
     else if (k == "fuse") { if (value < 1 || value > 4) return fail(LBM_ERR_ARG, "fuse must be 1, 2, 3 or 4 (4: tile kernel, no strip faces)"); c->fuse = (int)value; c->deep = 0; }
     else if (k == "deep") {     // k_stepd_tile: 1: 6 iterations on 64x16 tiles, 2: 7 on 64x16, 3: 8 on 32x32 (1024 threads);
-                                // 4 / 5: 5 / 6 iterations on 32x16 tiles (512 threads); k_stepc_col (registers): 6 / 7:
-                                // 5 / 6 iterations on 64x32 regions. 2 and 3: whole-domain launches only.
-        if (value < 0 || value > 7) return fail(LBM_ERR_ARG, "deep must be 0..7");
+                                // k_stepc_col (registers): 6 / 7: 5 / 6 iterations on 64x32 regions. 2 and 3: whole-domain launches only.
+        if (!deep_valid((int)value)) return fail(LBM_ERR_ARG, "deep must be 0..3, 6 or 7 (4 / 5, round 2's 32x16 LDS tiles, are retired)");
         c->deep = (int)value;
-        if (c->deep) { c->fuse = deep_depth(c->deep); c->slide = 0; }
+        if (c->deep) c->fuse = deep_depth(c->deep);
     }
     else if (k == "pair") c->fuse = (int)value ? 2 : 1;
     else if (k == "trailing_pair") c->trailing_pair = (int)value ? 1 : 0;
     else if (k == "xcd") c->xcd = (int)value ? 1 : 0;
-    else if (k == "slide") { c->slide = (int)value ? 1 : 0; if (c->slide) c->deep = 0; }
     else if (k == "arith") { if (value != 0 && value != 1) return fail(LBM_ERR_ARG, "arith must be 0 (strict) or 1 (contracted)"); c->arith = (int)value; }
     else if (k == "deep_halo") { c->deep_halo = (int)value ? 1 : 0; c->deep_pinned = true; }
     else if (k == "skip_exchange") c->skip_exchange = (int)value ? 1 : 0;
@@ -1947,11 +1887,10 @@ const char* lbm_kernel_name(const lbm_ctx* c) {
     const char* nt = c->use_nt ? "true" : "false";
     const int ar = c->arith;
     if (c->fuse > 2 && deep_is_col(c->deep)) snprintf(name, sizeof(name), "k_stepc_col<%s,%d,%d,%d,%s,%d>", t, COL_R, COL_NW, deep_depth(c->deep), nt, ar);
-    else if (c->fuse > 2 && c->deep) snprintf(name, sizeof(name), "k_stepd_tile<%s,%s,%d,%s,true,%d>", t, deep_tile(c->deep), deep_depth(c->deep), nt, ar);
-    else if (c->fuse > 1 && c->slide) snprintf(name, sizeof(name), "k_step_slide<%s,%d,6,%s,%d>", t, c->fuse, nt, ar);
-    else if (c->fuse == 4) snprintf(name, sizeof(name), "k_step4_tile<%s,8,%d,%s,%s,%d>", t, c->esize == 8 ? 1024 : 512, nt, c->xcd ? "true" : "false", ar);
-    else if (c->fuse > 1) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%s,%s,%d>", c->fuse, t, c->pair_ty,
-                                   c->pair_ty == 12 ? (c->fuse == 3 ? 1024 : 768) : 512, nt, c->xcd ? "true" : "false", ar);
+    else if (c->fuse > 2 && c->deep) snprintf(name, sizeof(name), "k_stepd_tile<%s,%s,%d,%d>", t, deep_tile(c->deep), deep_depth(c->deep), ar);
+    else if (c->fuse == 4) snprintf(name, sizeof(name), "k_step4_tile<%s,8,%d,%d>", t, c->esize == 8 ? 1024 : 512, ar);
+    else if (c->fuse > 1) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%d>", c->fuse, t, c->pair_ty,
+                                   c->pair_ty == 12 ? (c->fuse == 3 ? 1024 : 768) : 512, ar);
     else if (use_vec(c)) snprintf(name, sizeof(name), "k_step_vec<%s,%d,0,%s,%d>", t, (int)(16 / c->esize), nt, ar);
     else snprintf(name, sizeof(name), "k_step_site<%s,0,%s,%d>", t, nt, ar);
     return name;

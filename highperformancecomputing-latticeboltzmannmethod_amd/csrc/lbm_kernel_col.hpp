@@ -27,9 +27,11 @@
 
 namespace lbmk {
 
-// lane i <- lane i-1 (lane 0 keeps its own value) / lane i <- lane i+1 (lane 63 keeps its own value): full-wave DPP shifts
-__device__ __forceinline__ unsigned dpp_shr1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ unsigned dpp_shl1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false); }
+// lane i <- lane i-1 (lane 0 reads 0) / lane i <- lane i+1 (lane 63 reads 0): full-wave DPP shifts. bound_ctrl:0 with every
+// row and bank enabled leaves no lane that keeps an "old" value, so the instruction has no tied input and the compiler
+// needs no copy in front of it (with old = src it emitted one v_mov per shifted dword: 38 of ~390 vector instructions a level).
+__device__ __forceinline__ unsigned dpp_shr1(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned dpp_shl1(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true); }
 __device__ __forceinline__ double from_left(double v) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
     const unsigned lo = dpp_shr1((unsigned)u), hi = dpp_shr1((unsigned)(u >> 32));
@@ -67,8 +69,15 @@ __device__ __forceinline__ bool unstable_if(const T (&f)[Q], bool valid) {
 // edge — meet in the same L2 at the same time and every XCD streams whole lattice rows (149.6 -> 161.7 GLUPS at 4096x1024
 // fp64). A band-major walk (8..37 tile columns per band, so that y-neighbours meet in L2 too) was measured and is gone:
 // 141-147 GLUPS — a tile then touches 300 sub-rows that its XCD's other tiles do not share, and the TLB / DRAM-page
-// locality of the row-interleaved layout is lost (profiles/r03/README.md).
-// The grid is one-dimensional: cdiv(nx, OW) * (bands of both row ranges) blocks, rounded up to a multiple of 8.
+// locality of the row-interleaved layout is lost; walking 2..4 tile rows together column by column (y-neighbours adjacent in
+// the order) gains nothing at 4096x1024 and loses 12-25 % at 8192x2048 (profiles/r03/README.md).
+// The grid is one-dimensional: cdiv(nx, OW) * (bands of both row ranges) blocks, rounded up to a multiple of 8 — one block per
+// tile. PERSISTENT blocks (two per CU walking the tiles of their XCD's run in a loop, so that a wave which has stored its last
+// rows issues its next tile's loads at once) were built and measured: 123 GLUPS against 142 for the same binary launched
+// one block per tile — blocks that start together and take equally long stay phase-locked, and the two blocks of a CU then
+// load together and compute together instead of filling each other's gaps, which the dispatcher's staggered hand-out gives
+// for free; the loop also costs registers (every loop-invariant scalar offset wants an SGPR for the whole kernel: 106 SGPRs,
+// > 100 spilled, 164 -> 142 GLUPS even when launched one block per tile). Gone.
 template <typename T, int R, int NW, int D, bool NT, int AR = AR_STRICT>
 __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_col(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int H = R * NW, HW = D - 1, OW = 64 - 2 * HW, OH = H - 2 * HW, LW = 64 + 2;
@@ -157,7 +166,6 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
             __syncthreads();
             // from the wave below (its top row): f2 at x, f5 at x-1, f6 at x+1; from the wave above (its bottom row): f4, f7 at x+1, f8 at x-1
             T p2 = xb[w][0][1 + lane], p5 = xb[w][1][lane], p6 = xb[w][2][2 + lane];
-            const T h4 = xb[w + 2][3][1 + lane], h7 = xb[w + 2][4][2 + lane], h8 = xb[w + 2][5][lane];
             bool badl = false;
             const bool lane_ok = lane >= L - 1 && lane <= 64 - L;
 #pragma unroll
@@ -169,7 +177,7 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
                 f[0] = g[j][0]; f[1] = from_left(g[j][1]); f[3] = from_right(g[j][3]);
                 f[2] = p2; f[5] = p5; f[6] = p6;
                 if (j < R - 1) { f[4] = g[j + 1][4]; f[7] = from_right(g[j + 1][7]); f[8] = from_left(g[j + 1][8]); }
-                else { f[4] = h4; f[7] = h7; f[8] = h8; }
+                else { f[4] = xb[w + 2][3][1 + lane]; f[7] = xb[w + 2][4][2 + lane]; f[8] = xb[w + 2][5][lane]; }   // (read here, not after the barrier: six registers fewer are live across the rows below; the buffer is not rewritten before this wave has passed the next barrier)
                 const bool valid = lane_ok;
                 const int y = Yr + ry, yg = a.y_start + y;
                 bool store = L == D && lane >= HW && lane < 64 - HW && ry >= HW && ry < H - HW;

@@ -5,9 +5,9 @@
 //
 //     plane i, local row gy in [0, ny_loc+2*GR), column col:   base[i*plane + gy*pitch + col]
 //     interior cell (x, y)  <->  gy = y+GR, col = xoff + x      (xoff*sizeof(T) is a multiple of 128 B)
-// GR = 6 ghost rows on each side (strips exchange their six edge rows once per TWO launches of up to three fused
-// iterations: the first launch of such a pair also updates three ghost rows per internal face, redundantly with the
-// neighbour, so that the second one finds valid inputs); one ghost column on each side.
+// GR = 6 ghost rows on each side (a strip exchanges its six edge rows once per launch of up to six fused iterations, or once
+// per TWO launches of up to three: the first launch of such a pair also updates three ghost rows per internal face,
+// redundantly with the neighbour, so that the second one finds valid inputs); one ghost column on each side.
 // The two strides describe either of two layouts chosen by the host (lbm_hip.hip, "plan"):
 //     PLANAR          plane = rows*pitch0 (+pad), pitch = pitch0            nine separate planes
 //     ROW-INTERLEAVED plane = pitch0,             pitch = 9*pitch0          [gy][i][col]: the nine sub-rows of a
@@ -22,11 +22,11 @@
 //
 // Kernel families (within one arithmetic mode all evaluate the SAME per-cell operation sequence => bit-identical results):
 //   k_step_site / k_step_vec     one iteration per launch, 144 B of HBM traffic per lattice update (fp64)
-//   k_step2/3/4_tile             two / three / four iterations per launch over 64 x TY tiles, intermediate states in LDS:
-//                                84 / 50-60 B per update measured (production path: 93-95 GLUPS strict, 100-104 GLUPS
-//                                contracted at 4096x1024 fp64 on one MI355X)
-//   k_step_slide                 two / three iterations per launch, 64-wide column blocks marching in y over LDS rings
-//                                (no y re-reads: 49 B per update; tuner candidate)
+//   k_step2/3/4_tile             two / three / four iterations per launch over 64 x TY tiles, intermediate states in LDS
+//                                (what a call's last iterations, short strips and the strict mode's measurement use)
+//   k_stepd_tile                 six / seven / eight iterations on an LDS-filling tile: grids of a single round of blocks
+//   k_stepc_col                  (lbm_kernel_col.hpp) five / six iterations with the lattice of a 64x32 region held in
+//                                registers: the production kernel of large grids and tall strips
 //   k_init, k_macros, k_forces, k_halo_pack/unpack   set-up and the output cadence
 // Arithmetic modes of the collision (enum Arith): strict IEEE operation by operation (bit-identical to the CPU oracle)
 // or FMA-contracted with one reciprocal (what the reference's -ffast-math -mfma build permits; <= 1e-10).
@@ -386,9 +386,33 @@ __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
 template <typename T> struct K2Extra {
     const T* feq_in;
     int small;   // the buffer is below 4 GiB: the lean path of k_step3_tile may address it with 32-bit byte offsets
+    int xcd;     // remap the blocks so that every XCD walks one contiguous run of tiles (run-time: scalar index arithmetic only)
+    int nt;      // non-temporal stores (run-time in the fused tile kernels: one block-uniform branch around the nine stores)
 };
 
-template <typename T, int TY, int NTH, bool NT, bool XCD = false, int AR = AR_STRICT>
+// the nine stores of one cell, plain or non-temporal (block-uniform choice)
+template <typename T>
+__device__ __forceinline__ void store_pops(T* base, long plane, const T (&f)[Q], bool nt) {
+    if (nt) {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) __builtin_nontemporal_store(f[i], base + (long)i * plane);
+    } else {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) base[(long)i * plane] = f[i];
+    }
+}
+template <typename T>
+__device__ __forceinline__ void buf_store_pops(const T (&f)[Q], __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned planeB, bool nt) {
+    if (nt) {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) buf_store<true>(f[i], r, voff, soff + (unsigned)i * planeB);
+    } else {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) buf_store<false>(f[i], r, voff, soff + (unsigned)i * planeB);
+    }
+}
+
+template <typename T, int TY, int NTH, int AR = AR_STRICT>
 __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int TX = 64, RW = TX + 2, RH = TY + 2, LP = RW + 2;
     __shared__ T lds[Q][RH][LP];
@@ -396,7 +420,7 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
     // linear block id is remapped so that every XCD walks one contiguous run of tiles: horizontally adjacent tiles,
     // which share the cache lines at their common edge, then run on the same L2 at the same time.
     int bx = blockIdx.x, by = blockIdx.y;
-    if (XCD) {
+    if (e.xcd) {
         const int nb = gridDim.x * gridDim.y;
         int b = by * gridDim.x + bx;
         if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;
@@ -454,12 +478,7 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
         if (solid) continue;
         bgk_collide<T, AR>(f, a.tau_inv);
         const long c = (long)(y + GR) * a.pitch + a.xoff + x;
-#pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            T* p = a.dst + (long)i * a.plane + c;
-            if (NT) __builtin_nontemporal_store(f[i], p);
-            else *p = f[i];
-        }
+        store_pops(a.dst + c, a.plane, f, e.nt != 0);
     }
     if (bad) atomicMin(a.unstable_t, a.t + 1);
 }
@@ -472,13 +491,13 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
 //   phase 3  the tile: pull P_{t+2} from LDS, BCs, collide, store P_{t+3}.
 // HBM traffic per update ~ (1 + (TX+4)(TY+4)/(TX TY)) * 24 B (58 B at 64x12); redundant collisions 1.21x. Bit-identical to
 // three single launches (tests). Rows of neighbouring strips must be present three deep beyond the rows written.
-template <typename T, int TY, int NTH, bool NT, bool XCD, int AR = AR_STRICT>
+template <typename T, int TY, int NTH, int AR = AR_STRICT>
 __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int TX = 64, R1W = TX + 4, R1H = TY + 4, R2W = TX + 2, R2H = TY + 2, LP = R1W;
     static_assert(R2W * R2H <= 2 * NTH, "two region-2 cells per thread at most");
     __shared__ T lds[Q][R1H][LP];
     int bx = blockIdx.x, by = blockIdx.y;
-    if (XCD) {
+    if (e.xcd) {
         const int nb = gridDim.x * gridDim.y;
         int b = by * gridDim.x + bx;
         if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;
@@ -627,15 +646,10 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
             if (LEAN) {
                 const unsigned ub = (unsigned)(Y0 + GR) * pitchB + (unsigned)(a.xoff + X0) * (unsigned)sizeof(T);
                 const unsigned voff = (unsigned)ly * pitchB + (unsigned)lx * (unsigned)sizeof(T);
-#pragma unroll
-                for (int i = 0; i < Q; ++i) buf_store<NT>(f[i], rdst, voff, ub + (unsigned)i * planeB);
+                buf_store_pops(f, rdst, voff, ub, planeB, e.nt != 0);
             } else {
                 const long c = (long)(y + GR) * a.pitch + a.xoff + x;
-#pragma unroll
-                for (int i = 0; i < Q; ++i) {
-                    T* p = a.dst + (long)i * a.plane + c;
-                    if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
-                }
+                store_pops(a.dst + c, a.plane, f, e.nt != 0);
             }
         }
         if (bad) atomicMin(a.unstable_t, a.t + 2);
@@ -649,13 +663,13 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
 // HBM traffic per update ~ (1 + (TX+6)(TY+6)/(TX TY)) * 18 B; redundant collisions 1.45x at 64x8 — worth it where the
 // three-iteration kernel is close to the memory roof (fp32). Needs four valid rows beyond the rows written, so strips
 // (GR = 6 = 2 x 3) never use it; the plan measurement decides elsewhere. Bit-identical to four single launches (tests).
-template <typename T, int TY, int NTH, bool NT, bool XCD, int AR = AR_STRICT>
+template <typename T, int TY, int NTH, int AR = AR_STRICT>
 __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int TX = 64, HW = 3, R1W = TX + 2 * HW, R1H = TY + 2 * HW, LP = R1W;
     static_assert((R1W - 2) * (R1H - 2) <= 2 * NTH, "two cells per thread at most in the in-place levels");
     __shared__ T lds[Q][R1H][LP];
     int bx = blockIdx.x, by = blockIdx.y;
-    if (XCD) {
+    if (e.xcd) {
         const int nb = gridDim.x * gridDim.y;
         int b = by * gridDim.x + bx;
         if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;
@@ -778,8 +792,7 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs
             bgk_collide<T, AR>(f, a.tau_inv);
             const unsigned ub = (unsigned)(Y0 + GR) * pitchB + (unsigned)(a.xoff + X0) * (unsigned)sizeof(T);
             const unsigned voff = (unsigned)ly * pitchB + (unsigned)lx * (unsigned)sizeof(T);
-#pragma unroll
-            for (int i = 0; i < Q; ++i) buf_store<NT>(f[i], rdst, voff, ub + (unsigned)i * planeB);
+            buf_store_pops(f, rdst, voff, ub, planeB, e.nt != 0);
             continue;
         }
         const bool solid = near_cyl && is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
@@ -789,26 +802,18 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs
         if (solid) continue;
         bgk_collide<T, AR>(f, a.tau_inv);
         const long c = (long)(y + GR) * a.pitch + a.xoff + x;
-#pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            T* p = a.dst + (long)i * a.plane + c;
-            if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
-        }
+        store_pops(a.dst + c, a.plane, f, e.nt != 0);
     }
     if (bad) atomicMin(a.unstable_t, a.t + 3);
 }
 
-// D iterations per launch (D = 5..8) on a TX x TY tile: k_step4_tile generalised — level 1 from HBM into an LDS image of the
+// D iterations per launch (D = 6..8) on a TX x TY tile: k_step4_tile generalised — level 1 from HBM into an LDS image of the
 // (TX + 2(D-1)) x (TY + 2(D-1)) region, levels 2..D-1 in place (pull into registers, barrier, compute, overwrite, barrier),
-// level D the tile -> HBM. Two regimes use it (the plan measurement picks the shape):
-//   32x16 tiles, 512 threads, D = 5/6 (69 / 79 KB of LDS in fp64: TWO blocks per CU). With three iterations per launch
-//     the step is within 20 % of what HBM delivers; deeper fusion removes that bound but an LDS image that fills the CU
-//     leaves ONE block per CU, whose waves then all sit in the same phase (LDS pull, barrier, arithmetic, LDS write,
-//     barrier): VALU and LDS take turns instead of overlapping. Two half-size blocks per CU are two independent barrier
-//     groups that fill each other's gaps: 122 GLUPS at 4096x1024 fp64 against 104 (one 64x16 block) and 112 (k_step4_tile).
-//   64x16 / 32x32 tiles, 1024 threads, D = 6..8: grids so small that one launch is a single round of blocks. There the
-//     chip runs load -> compute -> store in lockstep, so the two memory phases are paid per LAUNCH: fusing more
-//     iterations divides them, at the price of ~1.5x redundant collisions that such a grid has VALU time to spare for.
+// level D the tile -> HBM, on 64x16 / 32x32 tiles of 1024 threads: for grids so small that one launch is a single round of
+// blocks. There the chip runs load -> compute -> store in lockstep, so the two memory phases are paid per LAUNCH: fusing more
+// iterations divides them, at the price of ~1.5x redundant collisions that such a grid has VALU time to spare for.
+// (Round 2's production shape — 32x16 tiles, 512 threads, D = 5/6, two blocks per CU: 125-130 GLUPS at 4096x1024 fp64 — is
+// superseded by k_stepc_col, which keeps the same region in registers instead of LDS, and is no longer built.)
 // Whole-domain launches only (rows outside the domain hold the permanent ghost values; a strip's ghost rows go GR = 6 deep).
 // waves per SIMD the register allocation may assume: as many blocks as the LDS image allows on a CU (at most 32 waves)
 template <typename T, int TX, int TY, int D>
@@ -818,7 +823,7 @@ constexpr int deep_waves_per_simd() {
     if (blocks * waves > 32) blocks = 32 / waves;
     return (blocks * waves) / 4 > 0 ? (blocks * waves) / 4 : 1;
 }
-template <typename T, int TX, int TY, int D, bool NT, bool XCD, int AR = AR_STRICT>
+template <typename T, int TX, int TY, int D, int AR = AR_STRICT>
 __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())) k_stepd_tile(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int NTH = TX * TY, HW = D - 1, R1W = TX + 2 * HW, R1H = TY + 2 * HW, LP = R1W;
     static_assert(D >= 3 && (NTH == 1024 || NTH == 512 || NTH == 256), "one tile cell per thread at the last level");
@@ -839,7 +844,7 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
         }
     };
     int bx = blockIdx.x, by = blockIdx.y;
-    if (XCD) {
+    if (e.xcd) {
         const int nb = gridDim.x * gridDim.y;
         int b = by * gridDim.x + bx;
         if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;
@@ -964,8 +969,7 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
                     bgk_collide<T, AR>(f, a.tau_inv);
                     const unsigned ub = (unsigned)(Y0 + GR) * pitchB + (unsigned)(a.xoff + X0) * (unsigned)sizeof(T);
                     const unsigned voff = (unsigned)ly * pitchB + (unsigned)lx * (unsigned)sizeof(T);
-#pragma unroll
-                    for (int i = 0; i < Q; ++i) buf_store<NT>(f[i], rdst, voff, ub + (unsigned)i * planeB);
+                    buf_store_pops(f, rdst, voff, ub, planeB, e.nt != 0);
                 } else {
                     const bool solid = near_cyl && is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
                     T rho_bc, u_out;
@@ -974,11 +978,7 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
                     if (!solid) {
                         bgk_collide<T, AR>(f, a.tau_inv);
                         const long c = (long)(y + GR) * a.pitch + a.xoff + x;
-#pragma unroll
-                        for (int i = 0; i < Q; ++i) {
-                            T* p = a.dst + (long)i * a.plane + c;
-                            if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
-                        }
+                        store_pops(a.dst + c, a.plane, f, e.nt != 0);
                     }
                 }
             }
@@ -987,181 +987,6 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
     };
     if (lean) run.template operator()<true>();
     else run.template operator()<false>();
-}
-
-// D iterations per launch with a SLIDING WINDOW in y (temporal blocking without y-overlap). A block owns a column of
-// TX = 64 cells and a segment of rows [S0, S1); it marches up the segment in bands of B rows. At band k, level l
-// (l = 1..D; level l holds P_{t+l}) computes the B rows starting at S0 + k*B + (D-l): level 1 leads, level D (the
-// rows stored to HBM) trails by D-1 rows. Level l+1 pulls from an LDS ring of level l that keeps B+2 rows: the band
-// just produced plus the last two rows of the previous band. Per (plane, row, column) a pull scheme reads every value
-// exactly once, so nothing is re-read in y; only the x-halo (D-1 columns per side at level 1, shrinking by one per
-// level) is recomputed, plus D-1, D-2, .. rows once per segment as warm-up. Against k_step3_tile (64x12 tile: 1.42x
-// cell reads, 1.21x collisions) a 64-wide column with 128-row segments reads 1.08x and computes 1.05x.
-//   waves 0..B-1 : "row waves", one row of the band each, lane = x (coalesced 512-B global rows, conflict-free LDS)
-//   wave  B      : "halo wave", the 2*(D-l) halo cells of each of the B rows at level l (idle at level D)
-// The level-1 inputs of band k+1 are loaded from HBM into registers BEFORE the levels 2..D of band k are computed
-// (software prefetch: the loads overlap the arithmetic inside a block); D-1 barriers per band. The block -> (column,
-// segment) map gives every XCD one run of x-adjacent columns at the same height, so the cache lines two columns share
-// at their common edge meet in the same L2. Same per-cell operation sequence as every other step kernel =>
-// bit-identical results (tests). LDS: (D-1)*(B+2)*9*(64+2(D-1))*sizeof(T) = 78,336 B at D=3, B=6, fp64: two blocks
-// per CU. The host sizes the segments so that all blocks are resident at once (no tail wave).
-struct SlideArgs { int seg_h, nseg1, nseg2, ncol; };
-
-template <typename T, int D, int B, bool NT, int AR = AR_STRICT>
-__global__ void __launch_bounds__((B + 1) * 64, 4) k_step_slide(const KArgs<T> a, const K2Extra<T> e, const SlideArgs s) {
-    constexpr int TX = 64, HW = D - 1, LW = TX + 2 * HW, NS = B + 2;
-    static_assert(D >= 2 && D <= 4 && 2 * HW * B <= 64, "the halo wave covers 2*(D-1) cells of each of the B rows");
-    __shared__ T ring[D - 1][NS][Q][LW];
-    __shared__ T s_feq[Q];      // permanent content of physical N/S ghost rows; in LDS so that the loop holds no vector-memory
-                                // load besides the prefetch (a global load here would drain the prefetch at its s_waitcnt)
-    if (threadIdx.x < Q) s_feq[threadIdx.x] = e.feq_in[threadIdx.x];
-    int b = blockIdx.x;
-    {
-        const int nb = gridDim.x;
-        if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;       // XCD j walks the j-th contiguous run of blocks
-    }
-    const int seg = b / s.ncol, col = b - seg * s.ncol;
-    int S0, S1;
-    if (seg < s.nseg1) { S0 = a.y_lo + seg * s.seg_h; S1 = min(S0 + s.seg_h, a.y_lo + a.y_cnt); }
-    else { S0 = a.y_lo2 + (seg - s.nseg1) * s.seg_h; S1 = min(S0 + s.seg_h, a.y_lo2 + a.y_cnt2); }
-    const int X0 = col * TX;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool halo_wave = (w == B);
-    const int K = (S1 - S0 + B - 1) / B;                        // bands 0..K-1; band -1 is the warm-up
-
-    // this thread's cell at level l of band kb (level-l rows of band kb start at S0 + kb*B + (D-l)); false: no cell here
-    auto cell_xy = [&](int l, int kb, int& x, int& y) -> bool {
-        const int hw = D - l, R = S0 + kb * B + hw;
-        if (!halo_wave) { x = X0 + lane; y = R + w; return true; }
-        if (hw == 0) return false;
-        const int r = lane / (2 * hw), h = lane - r * (2 * hw);
-        x = (h < hw) ? X0 - hw + h : X0 + TX + (h - hw);
-        y = R + r;
-        return r < B;
-    };
-    // ... and is it a row some output of this segment depends on?
-    auto cell = [&](int l, int kb, int& x, int& y) -> bool {
-        return cell_xy(l, kb, x, y) && y >= S0 - (D - l) && y < S1 + (D - l);
-    };
-    auto slot_of = [&](int y) -> int { return (y - S0 + 2 * NS) % NS; };
-    // byte-free LDS element index of ring `r`, row slot `sl`, plane i, column xx (24-bit multiply: one full-rate instruction)
-    auto ring_at = [&](int r, int sl, int i, int xx) -> T& { return (&ring[0][0][0][0])[__mul24(r * NS + sl, Q * LW) + i * LW + xx]; };
-
-    // Addressing: one uniform base per buffer + a 32-bit byte offset per access (the host launches this kernel only for
-    // buffers below 4 GiB), so that the nine plane addresses cost one vector add each instead of a hoisted 64-bit
-    // scalar pair per plane and buffer (the kernel is scalar-register bound).
-    const char* const sbase = reinterpret_cast<const char*>(a.src);
-    char* const dbase = reinterpret_cast<char*>(a.dst);
-    const unsigned pitchB = (unsigned)a.pitch * (unsigned)sizeof(T), planeB = (unsigned)a.plane * (unsigned)sizeof(T);
-    auto cell_off = [&](int x, int y) -> unsigned { return (unsigned)(y + GR) * pitchB + (unsigned)(a.xoff + x) * (unsigned)sizeof(T); };
-
-    // raw pulled populations of this thread's level-1 cell of band kb (left untouched where the cell is not computed)
-    auto fetch = [&](int kb, T (&v)[Q]) {
-        int x, y;
-        if (kb >= K || !cell(1, kb, x, y)) return;
-        const int yg = a.y_start + y;
-        if (yg < 0 || yg >= a.ny_glob || x < 0 || x >= a.nx) return;
-        const unsigned c = cell_off(x, y);
-#pragma unroll
-        for (int i = 0; i < Q; ++i)
-            v[i] = *reinterpret_cast<const T*>(sbase + (c + (unsigned)i * planeB - (unsigned)cy(i) * pitchB - (unsigned)(cx(i) * (int)sizeof(T))));
-    };
-
-    bool bad[D];
-#pragma unroll
-    for (int l = 0; l < D; ++l) bad[l] = false;
-    bool near_cyl = false;
-
-    // One cell of level L (1..D) of band kb: f = the pulled populations for L == 1, else pulled from the ring of L-1.
-    // LEAN (block-uniform, decided per iteration): every cell of the iteration is a fluid cell strictly inside the
-    // domain on a row that is needed — no boundary, solid, ghost or validity logic at all.
-    auto level = [&]<int L, bool LEAN>(int kb, T (&f)[Q]) {
-        int x, y;
-        if (LEAN ? !cell_xy(L, kb, x, y) : !cell(L, kb, x, y)) return;
-        const int yg = a.y_start + y;
-        const int xx = x - X0 + HW;
-        bool store = true;
-        bool inside = true;
-        if (!LEAN) {
-            const bool row_in = (yg >= 0 && yg < a.ny_glob), col_in = (x >= 0 && x < a.nx);
-            inside = row_in && col_in;
-            if (!inside) {
-                if (L == D) return;
-#pragma unroll
-                for (int i = 0; i < Q; ++i) f[i] = (row_in && !col_in) ? T(0) : s_feq[i];
-            }
-        }
-        if (inside) {
-            if (L > 1) {
-                int sl[3];                                      // slots of rows y-1, y, y+1
-#pragma unroll
-                for (int d = 0; d < 3; ++d) sl[d] = (y + d - 1 - S0 + 2 * NS) % NS;
-#pragma unroll
-                for (int i = 0; i < Q; ++i) f[i] = ring_at(L > 1 ? L - 2 : 0, sl[1 - cy(i)], i, xx - cx(i));
-            }
-            if (!LEAN) {
-                bool solid = false;
-                if (near_cyl) solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);   // block-uniform branch
-                T rho_bc, u_out;
-                if (!solid) apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
-                bad[L - 1] |= any_unstable(f);
-                bgk_collide<T, AR>(f, a.tau_inv);
-                if (near_cyl) {                    // solid cells keep w_i (the collision result of such a cell is discarded)
-                    if (L == D) store = !solid;
-                    else {
-#pragma unroll
-                        for (int i = 0; i < Q; ++i) f[i] = solid ? wgt<T>(i) : f[i];
-                    }
-                }
-            } else {
-                bad[L - 1] |= any_unstable(f);
-                bgk_collide<T, AR>(f, a.tau_inv);
-            }
-        }
-        if (L < D) {
-            const int sl = slot_of(y);
-#pragma unroll
-            for (int i = 0; i < Q; ++i) ring_at(L < D ? L - 1 : 0, sl, i, xx) = f[i];
-        } else if (store) {
-            const unsigned c = cell_off(x, y);
-#pragma unroll
-            for (int i = 0; i < Q; ++i) {
-                T* p = reinterpret_cast<T*>(dbase + (c + (unsigned)i * planeB));
-                if (NT) __builtin_nontemporal_store(f[i], p); else *p = f[i];
-            }
-        }
-    };
-
-    T nxt[Q];
-#pragma unroll
-    for (int i = 0; i < Q; ++i) nxt[i] = T(0);
-    fetch(-1, nxt);
-    __syncthreads();                                            // s_feq
-    // Iteration k: level 1 of band k (consumes the prefetched registers: the only point that waits for vector memory,
-    // and everything outstanding there — the loads of band k and the stores of band k-2 — was issued at least a third
-    // of an iteration earlier), prefetch of band k+1, level D of band k-1 (stores), then levels 2..D-1 of band k.
-    // ring[l-1] is written by level l between two barriers and read by level l+1 after the second one.
-    auto iteration = [&]<bool LEAN>(int k) {
-        T f[Q];
-        if (D == 2) {                                           // one ring: level 2 must have read it before level 1 rewrites it
-            level.template operator()<D, LEAN>(k - 1, f);
-            __syncthreads();
-        }
-        level.template operator()<1, LEAN>(k, nxt);
-        fetch(k + 1, nxt);
-        if (D > 2) level.template operator()<D, LEAN>(k - 1, f);
-        __syncthreads();
-        if constexpr (D >= 3) { level.template operator()<2, LEAN>(k, f); __syncthreads(); }
-        if constexpr (D >= 4) { level.template operator()<3, LEAN>(k, f); __syncthreads(); }
-    };
-    for (int k = -1; k <= K; ++k) {
-        // block-uniform: can any cell this iteration touches (all levels, halo included) be solid?
-        near_cyl = tile_near_cylinder(a, X0, S0 + (k - 1) * B, TX, 2 * B + HW, HW);
-        iteration.template operator()<false>(k);
-    }
-#pragma unroll
-    for (int l = 0; l < D; ++l)
-        if (bad[l]) atomicMin(a.unstable_t, a.t + l);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -169,12 +169,12 @@ int  lbm_load_state(lbm_ctx* c, const char* path);
  *                 last only for a context without strip faces;
  *                 "pair" 1 == "fuse" 2), "pair_ty" 8|12 tile height, "xcd" XCD-aware tile walk,
  *                 "trailing_pair" 1 lets an lbm_step call end on a fused launch (snapshots then need one more step)
- *                 "slide" 1 the sliding-window fused kernel (k_step_slide) instead of the 2-D tile kernels,
- *                 "deep" 1..5 the deep tile kernel (k_stepd_tile): 1 six iterations per launch on 64x16 tiles, 2 seven on
- *                 64x16, 3 eight on 32x32 (1024-thread blocks: grids of a single round of blocks), 4 / 5 five / six
- *                 iterations on 32x16 tiles (512-thread blocks, two per CU in fp64: large grids; a plan of this family
- *                 uses both depths to split a call without a slow tail). Strips use 1, 4, 5 (a ghost frame is six rows
- *                 deep) with one exchange per launch,
+ *                 "deep" 1..3, 6, 7: more iterations per launch. 1 / 2 / 3: six / seven / eight iterations on an LDS-filling
+ *                 64x16 / 64x16 / 32x32 tile (k_stepd_tile, 1024-thread blocks: grids of a single round of blocks); 6 / 7:
+ *                 five / six iterations with the lattice of a 64x32 region held in registers (k_stepc_col, 512-thread
+ *                 blocks, two per CU: large grids; a plan of this family uses both depths to split a call without a slow
+ *                 tail). Strips use 1, 6, 7 (a ghost frame is six rows deep) with one exchange per launch; 4 / 5 (round 2's
+ *                 32x16 LDS tiles) are retired,
  *                 "arith" 0 strict IEEE collision (bit-identical to the CPU oracle) | 1 FMA-contracted (<= 1e-10)
  *   strips:       "overlap" 0 launch and exchange serialised | 1 edge bands first, the exchange overlapped with the interior
  *                 rows of the SAME launch | 2 the exchange overlapped with the interior rows of the NEXT (extended)

@@ -42,18 +42,11 @@ PLANS = {
     # four iterations fused per launch (k_step4_tile, 64x8 tiles; strips fall back to three)
     "rowil-fuse4-nt-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1),
     "planar-fuse4-alt": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=4, pair_ty=8, xcd=0),
-    # sliding-window fused kernel (k_step_slide): column blocks marching in y, three / two iterations per launch
-    "planar-slide3-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=3, slide=1),
-    "rowil-slide3": dict(tune=0, layout=1, variant=1, nt=0, alternate=1, fuse=3, slide=1),
-    "rowil-slide2-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=2, slide=1),
     # six / seven / eight iterations per launch on an LDS-filling tile (k_stepd_tile; what a small grid's measurement picks);
     # calls whose length is no multiple of the depth finish with the four-/three-/two-iteration tile kernels
     "rowil-deep6-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=1),
     "planar-deep7-alt": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, pair_ty=8, xcd=0, deep=2),
     "rowil-deep8-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=3),
-    # five / six iterations per launch on 32x16 tiles with 512-thread blocks (two per CU in fp64: what a large grid's measurement picks)
-    "rowil-half5-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=4),
-    "planar-half6": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=5),
     # five / six iterations per launch with the lattice held in registers (k_stepc_col: 64x32 regions, DPP x-shifts, six LDS
     # values per wave and level; round 3's production kernel — what a large grid's measurement and the strip rule pick)
     "rowil-col5-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=6),
@@ -63,13 +56,10 @@ PLANS = {
     "fast-auto": dict(arith=1),
     "fast-site": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1, arith=1),
     "fast-vec-alt": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=1, arith=1),
-    "fast-slide3-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=3, slide=1, arith=1),
-    "fast-rowil-slide2": dict(tune=0, layout=1, variant=1, nt=0, alternate=0, fuse=2, slide=1, arith=1),
     "fast-rowil-fuse3-12-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
     "fast-planar-pair8": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, pair=1, pair_ty=8, arith=1),
     "fast-rowil-fuse4-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
     "fast-rowil-deep7": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=2, arith=1),
-    "fast-rowil-half5": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=4, arith=1),
     "fast-planar-deep8": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=3, arith=1),
     "fast-rowil-col6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
     "fast-planar-col5": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=6, arith=1),
@@ -89,7 +79,7 @@ def fused_depth(plan_opts, steps_left, done, of):
     deep = (plan_opts or {}).get("deep", 0)
     if deep:
         maxd = 3                                     # what is left of a segment goes to the three-/two-iteration kernels
-        depths = {1: (6,), 4: (6, 5), 5: (6, 5), 6: (6, 5), 7: (6, 5)}.get(deep, ())      # a strip's ghost rows go six deep: no 7 / 8
+        depths = {1: (6,), 6: (6, 5), 7: (6, 5)}.get(deep, ())      # a strip's ghost rows go six deep: no 7 / 8
         for d in depths:
             if steps_left >= d + 1 and all(of <= 0 or (done + j) % of != 0 for j in range(1, d)):
                 return d
@@ -194,8 +184,8 @@ def test_golden_unstable_timestep(lbm, name, plan):
     (64, 9, 45, dict(cylinder_x=-1.0, cylinder_radius=0.0)),          # a single tile column, partial second tile row
 ])
 @pytest.mark.parametrize("plan", ["auto", "planar-site", "rowil-vec-nt-alt", "planar-pair8-nt", "rowil-pair12-alt",
-                                  "planar-fuse3-8", "rowil-fuse3-12-nt-xcd", "planar-slide3-nt", "rowil-slide3",
-                                  "rowil-slide2-nt", "rowil-fuse4-nt-xcd", "planar-fuse4-alt"] + FAST)
+                                  "planar-fuse3-8", "rowil-fuse3-12-nt-xcd", "rowil-col5-nt", "planar-col6-alt",
+                                  "rowil-deep6-nt", "rowil-fuse4-nt-xcd", "planar-fuse4-alt"] + FAST)
 def test_against_oracle(lbm, nx, ny, steps, kw, plan):
     from oracle.oracle import Oracle, make_params
     of = max(1, steps // 5)
@@ -228,13 +218,13 @@ def test_against_oracle(lbm, nx, ny, steps, kw, plan):
 
 
 def test_contracted_arithmetic_is_plan_independent(lbm):
-    """Every kernel family evaluates the same contracted per-cell sequence: site / vector / sliding 2- and 3-step launches
-    and a strip decomposition give identical bits (so the result does not depend on the launch schedule)."""
+    """Every kernel family evaluates the same contracted per-cell sequence: site / vector / LDS-tile / register-column
+    launches and a strip decomposition give identical bits (so the result does not depend on the launch schedule)."""
     nx, ny, steps, of = 320, 90, 240, 60
     kw = dict(inlet_velocity=0.07, cylinder_radius=0.1)
     out = []
-    for plan in ("fast-site", "fast-vec-alt", "fast-slide3-nt", "fast-rowil-slide2", "fast-rowil-fuse3-12-xcd", "fast-planar-pair8",
-                 "fast-rowil-fuse4-xcd"):
+    for plan in ("fast-site", "fast-vec-alt", "fast-rowil-col6", "fast-planar-col5", "fast-rowil-fuse3-12-xcd", "fast-planar-pair8",
+                 "fast-rowil-fuse4-xcd", "fast-rowil-deep7", "fast-planar-deep8"):
         with lbm.Context(nx, ny, options=PLANS[plan], **kw) as ctx:
             ctx.initialise()
             ctx.step(steps, of)
@@ -244,7 +234,7 @@ def test_contracted_arithmetic_is_plan_independent(lbm):
         for u, v in zip(out[0][1], other[1]):
             assert np.array_equal(u, v)
     ctxs, _ = _run_strips(lbm, nx, ny, [(0, 40), (40, 13), (53, 37)], steps, of, pairs=True,
-                          plans=["fast-slide3-nt", "fast-slide3-nt", "fast-rowil-slide2"], **kw)
+                          plans=["fast-rowil-fuse3-12-xcd", "fast-planar-pair8", "fast-rowil-col6"], **kw)
     assert np.array_equal(np.concatenate([c.populations("f_next")[1:-1] for c in ctxs], axis=0), out[0][0][1:-1])
     for c in ctxs:
         c.close()
@@ -323,8 +313,8 @@ def test_strips_match_single_domain_bitwise(lbm):
 
 @pytest.mark.parametrize("strip_plans", [["planar-pair8-nt", "rowil-pair12-alt", "rowil-pair12-alt"],
                                          ["planar-fuse3-8", "rowil-fuse3-12-nt-xcd", "rowil-fuse3-12-nt-xcd"],
-                                         ["planar-slide3-nt", "rowil-slide3", "rowil-fuse3-12-nt-xcd"],
-                                         ["rowil-slide2-nt", "rowil-slide2-nt", "planar-pair8-nt"]])
+                                         ["planar-col6-alt", "rowil-col5-nt", "rowil-fuse3-12-nt-xcd"],
+                                         ["rowil-deep6-nt", "rowil-col5-nt", "planar-pair8-nt"]])
 def test_strips_with_fused_launches_match_single_domain_bitwise(lbm, strip_plans):
     """Strips whose launches fuse two / three iterations: the LBM_HALO_ROWS-deep halo makes the recomputed edge rows
     identical to the neighbour's own; result == the one-domain run, bit for bit."""
@@ -371,8 +361,8 @@ def test_overlap_choreography_with_loopback_halo(lbm, pair):
 
 
 @pytest.mark.parametrize("overlap,deep", [(1, 1), (0, 1), (1, 0), (0, 0), (2, 1), (2, 0)])
-@pytest.mark.parametrize("plan", ["rowil-fuse3-12-nt-xcd", "rowil-slide3", "rowil-site-nt", "fast-rowil-slide2",
-                                  "rowil-half5-nt", "fast-rowil-half5", "rowil-deep6-nt", "rowil-col5-nt", "fast-rowil-col6"])
+@pytest.mark.parametrize("plan", ["rowil-fuse3-12-nt-xcd", "rowil-pair12-alt", "rowil-site-nt", "fast-rowil-fuse3-12-xcd",
+                                  "rowil-deep6-nt", "rowil-col5-nt", "fast-rowil-col6"])
 def test_group_of_strips_on_one_device_matches_single_domain_bitwise(lbm, plan, overlap, deep):
     """In-process strips (lbm_group_*, the transport `lbm_solver --gpus N` uses) with the production choreography: edge
     bands on the side stream, every strip PULLING its neighbours' edge rows with exactly the pointers / offsets / counts
@@ -407,7 +397,7 @@ def test_group_of_strips_on_one_device_matches_single_domain_bitwise(lbm, plan, 
             g.ctxs[0].step(1, 0)
 
 
-@pytest.mark.parametrize("plan", [None, "rowil-half5-nt", "rowil-deep6-nt", "rowil-deep8-nt", "rowil-col5-nt", "planar-col6-alt"])
+@pytest.mark.parametrize("plan", [None, "rowil-deep6-nt", "rowil-deep8-nt", "rowil-col5-nt", "planar-col6-alt"])
 def test_host_staged_strips_calling_patterns(lbm, plan):
     """The MPI-hosted calling pattern of INTEGRATION.md §C: lbm_step(4) = a fused launch of three iterations + a single
     one, then the caller exchanges the edge rows — on contexts that measured their own plan (None: large enough to time the
@@ -511,7 +501,7 @@ def test_group_checkpoint_restart(lbm, tmp_path):
     """Per-strip checkpoints of a group, restored into a fresh group (lbm_group_refresh_halos), continue bit-exactly."""
     nx, ny = 256, 96
     kw = dict(inlet_velocity=0.07, cylinder_radius=0.1)
-    with lbm.Group(nx, ny, 3, options=PLANS["rowil-slide3"], **kw) as a:
+    with lbm.Group(nx, ny, 3, options=PLANS["rowil-fuse3-12-nt-xcd"], **kw) as a:
         a.initialise()
         a.step(137, 0)
         for k, c in enumerate(a.ctxs):
@@ -559,12 +549,11 @@ def test_checkpoint_restart_is_bit_exact(lbm, tmp_path):
 
 
 @pytest.mark.parametrize("plan,steps,of,trailing,launches", [
-    ("rowil-half5-nt", 20, 0, 1, 4),        # 5+5+5+5
-    ("planar-half6", 22, 0, 1, 4),          # 6+6+5+5: the 32x16 family uses both of its depths
+    ("rowil-col5-nt", 20, 0, 1, 4),         # 5+5+5+5
     ("rowil-deep6-nt", 20, 0, 1, 4),        # 6+6+4+4 rather than 6+6+6+2
     ("rowil-deep8-nt", 19, 0, 1, 3),        # 8+8+3
-    ("rowil-half5-nt", 20, 0, 0, 5),        # 5+5+5+4 and the single last iteration of a call that may be read back
-    ("rowil-half5-nt", 24, 10, 1, 5),       # force outputs at 10 and 20 end the fused segments: 5+5 | 5+5 | 4
+    ("rowil-col5-nt", 20, 0, 0, 5),         # 5+5+5+4 and the single last iteration of a call that may be read back
+    ("rowil-col5-nt", 24, 10, 1, 5),        # force outputs at 10 and 20 end the fused segments: 5+5 | 5+5 | 4
     ("rowil-fuse3-12-nt-xcd", 20, 0, 1, 6), # 4+4+3+3+3+3
     ("rowil-col5-nt", 22, 0, 1, 4),         # 6+6+5+5: the register-column family uses both of its depths too
     ("planar-col6-alt", 20, 0, 0, 5),       # 5+5+5+4 and the single last iteration
@@ -806,7 +795,7 @@ def test_fp32_tracks_the_oracle_on_fused_plans_1024x256(lbm):
         er, eu = macro_errors(*ctx.macros(), *ref)
         assert er < TOL and eu < TOL, (er, eu)
     out = {}
-    for plan in ("auto", "rowil-fuse3-12-nt-xcd", "rowil-fuse4-nt-xcd", "planar-slide3-nt", "rowil-slide2-nt", "planar-site",
+    for plan in ("auto", "rowil-fuse3-12-nt-xcd", "rowil-fuse4-nt-xcd", "rowil-deep6-nt", "rowil-pair12-alt", "planar-site",
                  "rowil-col5-nt", "planar-col6-alt"):
         with lbm.Context(nx, ny, precision="f32", options=PLANS[plan], **kw) as ctx:
             ctx.initialise()
@@ -865,13 +854,13 @@ def test_c5_grid_16384x4096_fp32_single_gpu(lbm):
     print(f"C5 fp32 vs fp64 (HIP) x {steps}: rho {er:.3e}, u {eu:.3e}, force {ef:.3e}")
     del m64
     assert er < 2e-5 and eu < 2e-4 and ef < 1e-4, (er, eu, ef)
-    for options in (None, PLANS["rowil-fuse3-12-nt-xcd"], PLANS["rowil-half5-nt"], PLANS["planar-slide3-nt"], PLANS["rowil-site-nt"]):
+    for options in (None, PLANS["rowil-fuse3-12-nt-xcd"], PLANS["rowil-col5-nt"], PLANS["rowil-deep6-nt"], PLANS["rowil-site-nt"]):
         m2, log2, _, _ = run(options)
         for a, b in zip((rho, ux, uy), m2):
             assert np.array_equal(a, b), options
         assert log2 == log
         del m2
-    with lbm.Group(nx, ny, 8, options=dict(PLANS["rowil-slide3"]), **kw) as g:
+    with lbm.Group(nx, ny, 8, options=dict(PLANS["rowil-fuse3-12-nt-xcd"]), **kw) as g:
         assert g.initialise() == 130721
         g.step(steps, 150)
         assert g.first_unstable_step() == -1

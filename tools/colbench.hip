@@ -1,7 +1,7 @@
 // tools/colbench.hip — development harness of the register-resident column kernel k_stepc_col (tuning tool, not part of
 // the product or the parity path): every shape is first held bit for bit against D single-iteration launches of
 // k_step_site on a small grid with every boundary and the cylinder inside, then timed on the headline grid next to the
-// LDS-image kernel k_stepd_tile<32,16,5>.
+// LDS-image kernel k_stepd_tile<32,16,5> (round 2's production shape, no longer built into the library).
 //
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -o tools/colbench tools/colbench.hip
 #include "../highperformancecomputing-latticeboltzmannmethod_amd/csrc/lbm_kernel_col.hpp"
@@ -55,7 +55,7 @@ struct Lattice {
         a.tau_inv = (T)(1.0 / 0.6); a.u_in = (T)u_in; a.unstable_t = d_unst; a.t = depth_t;
         return a;
     }
-    K2Extra<T> extra() { K2Extra<T> e; e.feq_in = d_feq; e.small = (total * sizeof(T) + 4096 < (size_t(1) << 32)) ? 1 : 0; return e; }
+    K2Extra<T> extra() { K2Extra<T> e; e.feq_in = d_feq; e.xcd = 1; e.nt = 1; e.small = (total * sizeof(T) + 4096 < (size_t(1) << 32)) ? 1 : 0; return e; }
     void init() {
         InitArgs<T> ia;
         ia.a = A; ia.b = B; ia.plane = plane; ia.pitch = pitch; ia.xoff = xoff; ia.nx = nx; ia.ny_loc = ny;
@@ -89,14 +89,16 @@ struct Lattice {
 template <typename T> struct Variant { std::string name; int depth; std::function<void(Lattice<T>&)> launch; };
 
 template <typename T, int R, int NW, int D, int AR>
-Variant<T> col_variant(bool nt) {
+Variant<T> col_variant(bool nt, bool alt = false, int persist = 0) {
     char nm[96];
-    snprintf(nm, sizeof(nm), "col R=%d NW=%d D=%d %s", R, NW, D, nt ? "nt" : "  ");
+    snprintf(nm, sizeof(nm), "col R=%d NW=%d D=%d %s %s p%d", R, NW, D, nt ? "nt" : "  ", alt ? "alt" : "", persist);
     return {nm, D, [=](Lattice<T>& L) {
         constexpr int OW = 64 - 2 * (D - 1), OH = R * NW - 2 * (D - 1);
         const int nb = ((L.nx + OW - 1) / OW) * ((L.ny + OH - 1) / OH);
+        (void)persist;
         dim3 grid((nb + 7) / 8 * 8);
         KArgs<T> a = L.args(L.t);
+        a.reverse = alt ? (L.cur & 1) : 0;       // walk the tile rows top-down on every other launch
         if (nt) hipLaunchKernelGGL((k_stepc_col<T, R, NW, D, true, AR>), grid, dim3(NW * 64), 0, L.s, a, L.extra());
         else hipLaunchKernelGGL((k_stepc_col<T, R, NW, D, false, AR>), grid, dim3(NW * 64), 0, L.s, a, L.extra());
     }};
@@ -108,7 +110,7 @@ Variant<T> tile_variant() {
     return {nm, D, [=](Lattice<T>& L) {
         dim3 grid((L.nx + TX - 1) / TX, (L.ny + TY - 1) / TY);
         KArgs<T> a = L.args(L.t);
-        hipLaunchKernelGGL((k_stepd_tile<T, TX, TY, D, true, true, AR>), grid, dim3(TX * TY), 0, L.s, a, L.extra());
+        hipLaunchKernelGGL((k_stepd_tile<T, TX, TY, D, AR>), grid, dim3(TX * TY), 0, L.s, a, L.extra());
     }};
 }
 
@@ -119,6 +121,7 @@ std::vector<Variant<T>> variants() {
     v.push_back(col_variant<T, 4, 8, 5, AR>(true));
     v.push_back(col_variant<T, 4, 8, 6, AR>(true));
     v.push_back(col_variant<T, 4, 8, 6, AR>(false));
+    v.push_back(col_variant<T, 4, 8, 6, AR>(false, true));
     return v;
 }
 
@@ -199,7 +202,7 @@ void timeit(int nx, int ny, int reps, int rounds, const std::string& filter) {
 
 int main(int argc, char** argv) {
     int nx = 4096, ny = 1024, reps = 100, rounds = 3;
-    bool do_check = true, do_time = true;
+    bool do_check = true, do_time = true, strict = false;
     std::string prec = "f64", filter;
     int mnx = 0, mny = 0, mlaunch = 1;
     for (int i = 1; i < argc; ++i) {
@@ -211,6 +214,7 @@ int main(int argc, char** argv) {
         else if (k == "--prec") prec = argv[++i];
         else if (k == "--no-check") do_check = false;
         else if (k == "--no-time") do_time = false;
+        else if (k == "--strict") strict = true;
         else if (k == "--filter") filter = argv[++i];
         else if (k == "--map") { g_map = true; mnx = atoi(argv[++i]); mny = atoi(argv[++i]); mlaunch = atoi(argv[++i]); }
     }
@@ -223,7 +227,7 @@ int main(int argc, char** argv) {
         fflush(stdout);
     }
     if (do_time && !failures) {
-        if (prec == "f64") timeit<double, AR_CONTRACTED>(nx, ny, reps, rounds, filter);
+        if (prec == "f64") { timeit<double, AR_CONTRACTED>(nx, ny, reps, rounds, filter); if (strict) timeit<double, AR_STRICT>(nx, ny, reps, rounds, filter); }
         else timeit<float, AR_CONTRACTED>(nx, ny, reps, rounds, filter);
     }
     return failures ? 1 : 0;

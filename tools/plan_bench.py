@@ -22,11 +22,6 @@ PLANS = {
     "tile2": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=2, pair_ty=12, xcd=0),
     "tile3": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=0),
     "tile3-rowil": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1),
-    "slide3": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, fuse=3, slide=1),
-    "slide3-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=3, slide=1),
-    "slide3-rowil": dict(tune=0, layout=1, variant=1, nt=0, alternate=0, fuse=3, slide=1),
-    "slide3-rowil-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, slide=1),
-    "slide2-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=2, slide=1),
     "fast-tile3": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=0, arith=1),
     "fast-tile3-rowil-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
     "fast-tile3-rowil-xcd-8": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=8, xcd=1, arith=1),
@@ -39,24 +34,18 @@ PLANS = {
     "tile4": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1),
     "fast-tile4": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
     "fast-tile4-planar": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
+    "fast-col5": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=6, arith=1),
+    "fast-col6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
+    "fast-col6-nt0": dict(tune=0, layout=1, variant=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
+    "col6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7),
     "fast-deep6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=1, arith=1),
     "fast-deep7": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=2, arith=1),
     "fast-deep8": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=3, arith=1),
-    "fast-half5": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=4, arith=1),
-    "fast-half6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=5, arith=1),
-    "fast-half5-planar": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, pair_ty=12, xcd=1, deep=4, arith=1),
-    "fast-half5-nt0": dict(tune=0, layout=1, variant=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=4, arith=1),
-    "half5": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=4),
-    "half6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=5),
     "deep7": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=2),
     "deep8": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=3),
     "fast-auto": dict(arith=1),
     "fast-site": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1, arith=1),
     "fast-vec": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=1, arith=1),
-    "fast-slide3": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, fuse=3, slide=1, arith=1),
-    "fast-slide3-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=3, slide=1, arith=1),
-    "fast-slide3-rowil-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, slide=1, arith=1),
-    "fast-slide2-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=2, slide=1, arith=1),
 }
 
 
@@ -68,7 +57,7 @@ def main():
     ap.add_argument("--precision", default="f64")
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--plans", default="tile3,slide3,slide3-nt,slide3-rowil,slide3-rowil-nt")
+    ap.add_argument("--plans", default="tile3")
     ap.add_argument("--set", action="append", default=[], help="extra option key=value applied to every plan")
     args = ap.parse_args()
     u_in = args.re * ((0.6 - 0.5) / 3.0) / (2.0 * 0.05 * args.ny)
