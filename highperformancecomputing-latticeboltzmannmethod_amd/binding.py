@@ -71,6 +71,7 @@ def lib():
         L.lbm_load_state.argtypes = [vp, C.c_char_p]
         L.lbm_last_step_kernel_ms.argtypes = [vp, dp]
         L.lbm_last_step_stats.argtypes = [vp, dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.lbm_graph_replays.restype = C.c_long; L.lbm_graph_replays.argtypes = [vp]
         L.lbm_kernel_name.argtypes = [vp]; L.lbm_kernel_name.restype = C.c_char_p
         L.lbm_plan.argtypes = [vp]; L.lbm_plan.restype = C.c_char_p
         L.lbm_build_id.restype = C.c_char_p
@@ -252,6 +253,10 @@ class Context:
         ms, nl, ni = C.c_double(), C.c_int(), C.c_int()
         self._chk(self.L.lbm_last_step_stats(self.h, C.byref(ms), C.byref(nl), C.byref(ni)))
         return ms.value, nl.value, ni.value
+
+    def graph_replays(self):
+        """Replays of the captured launch-group graph so far (strips with a device transport on a deep plan)."""
+        return int(self.L.lbm_graph_replays(self.h))
 
     def last_step_kernel_ms(self):
         v = C.c_double()

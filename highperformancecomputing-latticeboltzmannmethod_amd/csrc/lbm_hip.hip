@@ -175,7 +175,7 @@ struct lbm_ctx {
     int overlap = 1;
     bool overlap_pinned = false, deep_pinned = false;   // set through lbm_set_option: the strip tuner leaves them alone
     int skip_exchange = 0;   // DIAGNOSTIC: issue every launch but no halo traffic (times the compute side of a strip run; results invalid)
-    char sched_desc[96] = "";
+    char sched_desc[256] = "";
     int timed_launches = 0, timed_steps = 0;
     long launches_total = 0;
     // communicator
@@ -192,6 +192,17 @@ struct lbm_ctx {
     std::shared_ptr<GroupPool> pool;   // the group's host threads (shared by its members)
     int edge_rows[2] = {0, 0};   // edge-band heights of the launch in flight (issue_before -> issue_after)
     bool ext_split_pending = false;   // overlap 2: the edge part of the last extended launch is queued on the side stream (ev_edge)
+    // hipGraph replay of launch groups (a strip with a device transport on a deep plan; see replay_groups)
+    int use_graph = 1;               // option "graph"
+    hipGraphExec_t gexec = nullptr;  // GRAPH_GROUPS consecutive launch groups captured from the eager path
+    int gkey[6] = {0, 0, 0, 0, 0, 0};   // what the capture depended on: cur, overlap, deep_halo, deep, use_nt, skip_exchange
+    int giters = 0;                  // iterations one replay advances
+    bool graph_failed = false;       // capture was refused once (e.g. by the transport): eager from then on
+    hipEvent_t gev_main = nullptr, gev_edge = nullptr, gev_comm = nullptr;   // the capture's own events (a captured event must not be waited for eagerly)
+    int* d_tbase = nullptr;          // device word the kernels' iteration numbers are relative to (KArgs::t_base)
+    int tbase_host = 0;              // its value as of the work queued so far
+    long graph_replays = 0;
+    char graph_note[128] = "";       // why the graph path was given up, if it was
     // host-staged halo staging (device side)
     double* d_halo = nullptr;  // 4 faces-in-flight x [GR][9][nx] doubles
 };
@@ -216,7 +227,8 @@ KArgs<T> make_kargs(const lbm_ctx* c, int src, int dst, int t) {
     a.tau_inv = (T)(1.0 / c->p.tau);
     a.u_in = (T)c->p.inlet_velocity;
     a.unstable_t = c->d_unstable;
-    a.t = t;
+    a.t = t - c->tbase_host;
+    a.t_base = c->d_tbase;
     a.y_lo = 0;
     a.y_cnt = c->nyl;
     a.y_lo2 = 0;
@@ -846,21 +858,33 @@ int choose_plan(lbm_ctx* c) {
     // the strip rule (see below): a function of the global grid and the number of strips only, so that every rank —
     // measuring or not — issues the same launch depths
     const int nstrips = c->group_n > 1 ? c->group_n : (c->comm && c->nranks > 1) ? c->nranks : 1;
-    const bool strip_deep = strips && c->p.ny / nstrips >= 64;
+    // 0: three iterations on 64x12 LDS tiles in pairs between exchanges; 1: six iterations on 64x16 LDS tiles of 1024 threads
+    // (one cell per thread: the shortest launch, and on strips this short the chain edge band -> exchange -> edge band IS
+    // the time step); 7: six iterations on 64x32 regions held in registers (four cells per thread: the highest throughput).
+    // One GPU, one rank of N exchanging with itself through RCCL, 4096 columns (tools/strip_proxy.py, profiles/r03): 128 rows
+    // 7.6 us per iteration on the LDS tiles against 8.5 in registers; 256 rows 13.2 against 11.6.
+    const int strip_rows = c->p.ny / nstrips;
+    const int strip_deep = !strips ? 0 : strip_rows >= 192 ? 7 : strip_rows >= 64 ? 1 : 0;
+    const char* const deep_name[2] = {"row-interleaved/6-step 64x16", "row-interleaved/6-step 64x32 in registers"};
+    static thread_local char dn[3][96];
+    if (strip_deep) {
+        snprintf(dn[0], sizeof(dn[0]), "%s (default, not measured)", deep_name[strip_deep == 7]);
+        snprintf(dn[1], sizeof(dn[1]), "%s/nt-store/xcd", deep_name[strip_deep == 7]);
+        snprintf(dn[2], sizeof(dn[2]), "%s/xcd", deep_name[strip_deep == 7]);
+    }
     if (!c->tune) cand.push_back(fixed);
     else if (!can_tune) {
-        if (strip_deep) cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers (default, not measured)", 7});
+        if (strip_deep) cand.push_back({1, 1, 1, 0, 6, 12, 1, dn[0], strip_deep});
         else if (strips) cand.push_back({1, 1, 1, 0, p2 ? 3 : 1, 12, 1, "row-interleaved (default, not measured)"});
         else cand.push_back({0, vec_ok ? 0 : 1, 1, 0, p2 ? 3 : 1, 12, 0, "planar (default, not measured)"});
     } else {
         // Strips exchange GR rows x 9 sub-rows as one contiguous run: row-interleaved only. Every rank must issue the
-        // same sequence of launches (one exchange per launch), so the fusion depth and tile height of a strip run are
-        // fixed by rule — a function of the global grid and the number of strips only: 6 iterations on 32x16 tiles where
-        // a strip has 64 rows or more, else 3 iterations on 64x12 tiles; only rank-local choices are measured.
+        // same sequence of launches (one exchange per launch), so the fusion depth and tile shape of a strip run are
+        // fixed by rule — a function of the global grid and the number of strips only (above); only rank-local choices
+        // (the store policy) are measured.
         if (strip_deep) {
-            // tall strips: six (five) iterations per launch on 64x32 regions held in registers, one exchange of the GR rows after every launch
-            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-store/xcd", 7});
-            cand.push_back({1, 1, 0, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/xcd", 7});
+            cand.push_back({1, 1, 1, 0, 6, 12, 1, dn[1], strip_deep});
+            cand.push_back({1, 1, 0, 0, 6, 12, 1, dn[2], strip_deep});
         } else if (strips) {
             const int f = p2 ? 3 : 1;
             cand.push_back({1, 1, 1, 0, f, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
@@ -971,15 +995,31 @@ template <typename T> int do_steps(lbm_ctx** cs, int n, int nsteps, int of);
 int allreduce_doubles(lbm_ctx* c, double* vals, int n, int op);
 
 // Strip schedule by measurement (one rank of a multi-process run; collective: every rank runs the same trials and sees
-// the same reduced timings, so all ranks choose alike). The four schedules — exchange overlapped with the interior rows
-// or serialised, one exchange per two launches (deep halo) or per launch — compute identical results; which is fastest
-// depends on the strip height and on the link (overlap costs two extra launches and three events per group, which a
-// short strip cannot hide). 6 warm-up + 24 timed iterations each with the real transport, MAX over the ranks.
+// the same reduced timings, so all ranks choose alike). The schedules — exchange overlapped with the interior rows of the
+// same launch (1), of the next, extended launch (2) or serialised (0); one exchange per two launches (deep halo) or per
+// launch — compute identical results; which is fastest depends on the strip height and on the link (overlap costs two extra
+// launches and three events per group, which a short strip cannot hide). Each candidate: 60 warm-up + 240 timed iterations
+// (forty launch groups of six) with the real transport, MAX over the ranks; then the two fastest are timed again, twice,
+// and the faster of the two wins (candidates 2-3 % apart are common: round 2's single window of four groups could not rank
+// them). What travels per exchange and face is the same in every schedule — GR rows x 9 populations, one contiguous message
+// — so the payload per iteration depends on the iterations between two exchanges only; lbm_strip_schedule() reports it.
 template <typename T>
 int tune_strip_schedule(lbm_ctx* c) {
     const bool multi = c->comm && (c->nranks > 1 || c->loopback == 2);
-    snprintf(c->sched_desc, sizeof(c->sched_desc), "overlap=%d deep_halo=%d (%s)", c->overlap, c->deep_halo,
-             multi ? "fixed by options" : "default");
+    auto describe = [&](const char* how, int tried, double us_per_it) {
+        // iterations between two exchanges: a deep launch (up to GR iterations) exchanges after every launch; the
+        // three-iteration plans after every launch, or after every second one with the deep halo
+        const bool deep_launches = c->deep && deep_depth(c->deep) <= GR;
+        const int its = deep_launches ? deep_depth(c->deep) : std::min(c->fuse, 3) * (c->deep_halo ? 2 : 1);
+        const double face_bytes = (double)GR * c->pitch * c->esize;
+        int n = snprintf(c->sched_desc, sizeof(c->sched_desc), "overlap=%d deep_halo=%d (%s", c->overlap, c->deep_halo, how);
+        if (tried > 0 && n > 0 && n < (int)sizeof(c->sched_desc))
+            n += snprintf(c->sched_desc + n, sizeof(c->sched_desc) - n, " of %d measured, %.2f us/iteration", tried, us_per_it);
+        if (n > 0 && n < (int)sizeof(c->sched_desc))
+            snprintf(c->sched_desc + n, sizeof(c->sched_desc) - n, "); %.0f B per face and exchange = %.0f B per face and iteration (%d iterations per exchange)",
+                     face_bytes, face_bytes / std::max(its, 1), its);
+    };
+    describe(multi ? "fixed by options" : "default", 0, 0.0);
     if (!multi) return LBM_OK;
     {   // The trials below are COLLECTIVE (send/recv with the neighbours, an all-reduce per schedule): whether they run must be
         // the same decision on every rank. Strips may differ in height (191 rows over 8 ranks: seven of 24 and one of 23) and,
@@ -989,20 +1029,17 @@ int tune_strip_schedule(lbm_ctx* c) {
         if (rc) return rc;
         if (go < 0.5) return LBM_OK;
     }
-    const int keep_overlap = c->overlap, keep_deep = c->deep_halo, keep_tp = c->trailing_pair;
-    double best_ms = 1e30;
-    int best_o = keep_overlap, best_d = keep_deep, tried = 0;
+    const int keep_tp = c->trailing_pair;
     c->trailing_pair = 1;
-    static const int variants[5][2] = {{1, 1}, {0, 1}, {2, 1}, {1, 0}, {0, 0}};   // (overlap, deep_halo); 2 needs the deep halo
-    for (int v = 0; v < 5; ++v) {
-        const int o = variants[v][0], d = variants[v][1];
+    constexpr int WARM = 60, TIMED = 240;      // (the warm-up is long enough to take the one-off graph capture of a schedule)
+    auto trial = [&](int o, int d, double* worst_ms) -> int {
         c->overlap = o; c->deep_halo = d;
-        int rc = do_steps<T>(&c, 1, 6, 0);
+        int rc = do_steps<T>(&c, 1, WARM, 0);
         if (rc) return rc;
         rc = join_comm(c);
         if (rc) return rc;
         HIPCHK(hipEventRecord(c->ev_t0, c->stream));
-        rc = do_steps<T>(&c, 1, 24, 0);
+        rc = do_steps<T>(&c, 1, TIMED, 0);
         if (rc) return rc;
         rc = join_comm(c);
         if (rc) return rc;
@@ -1010,15 +1047,38 @@ int tune_strip_schedule(lbm_ctx* c) {
         HIPCHK(hipEventSynchronize(c->ev_t1));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
-        double worst = (double)ms;
-        rc = allreduce_doubles(c, &worst, 1, 1);       // MAX over the ranks: the job advances at the pace of its slowest strip
+        *worst_ms = (double)ms;
+        return allreduce_doubles(c, worst_ms, 1, 1);   // MAX over the ranks: the job advances at the pace of its slowest strip
+    };
+    static const int variants[5][2] = {{1, 1}, {0, 1}, {2, 1}, {1, 0}, {0, 0}};   // (overlap, deep_halo); 2 needs the deep halo
+    struct Res { int o, d; double ms; };
+    std::vector<Res> res;
+    for (int v = 0; v < 5; ++v) {
+        Res r{variants[v][0], variants[v][1], 0.0};
+        if (c->overlap_pinned && r.o != c->overlap) continue;        // (a pinned half of the schedule stays as set)
+        if (c->deep_pinned && r.d != c->deep_halo) continue;
+        int rc = trial(r.o, r.d, &r.ms);
         if (rc) return rc;
-        ++tried;
-        if (worst < best_ms) { best_ms = worst; best_o = o; best_d = d; }
+        res.push_back(r);
     }
-    c->overlap = best_o; c->deep_halo = best_d; c->trailing_pair = keep_tp;
-    snprintf(c->sched_desc, sizeof(c->sched_desc), "overlap=%d deep_halo=%d (fastest of %d measured, %.2f us/iteration)", best_o,
-             best_d, tried, best_ms * 1e3 / 24.0);
+    const int tried = (int)res.size();
+    std::stable_sort(res.begin(), res.end(), [](const Res& x, const Res& y) { return x.ms < y.ms; });
+    if (res.size() > 2) res.resize(2);
+    if (res.size() == 2) {
+        for (Res& r : res) {        // every rank re-times the same two in the same order (the reduced timings are identical everywhere)
+            double a = 0.0, b = 0.0;
+            int rc = trial(r.o, r.d, &a);
+            if (!rc) rc = trial(r.o, r.d, &b);
+            if (rc) return rc;
+            r.ms = std::min(a, b);
+        }
+        std::stable_sort(res.begin(), res.end(), [](const Res& x, const Res& y) { return x.ms < y.ms; });
+    }
+    c->trailing_pair = keep_tp;
+    if (!res.empty()) {
+        c->overlap = res[0].o; c->deep_halo = res[0].d;
+        describe("fastest", tried, res[0].ms * 1e3 / TIMED);
+    }
     // back to iteration 0 with fresh halos
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipStreamSynchronize(c->comm_stream));
@@ -1045,6 +1105,117 @@ int do_initialise(lbm_ctx* c) {
         if (rc) return rc;
     }
     return LBM_OK;
+}
+
+// ---- hipGraph replay of launch groups ------------------------------------------------------------------------
+// A strip of an N = 8 run (4096 x 128) advances six iterations in ~25 us of GPU time, and one launch group — edge-band
+// launch, three event records, three cross-stream waits, one RCCL group, interior launch — costs the host 33-43 us to issue:
+// the strip is host-bound (round 2's proxy: 7.7 us per iteration against 5.9-6.1 on the GPU). GRAPH_GROUPS consecutive groups
+// are therefore captured ONCE from the very code that issues them eagerly (plan_launch / issue_before / exchange_rccl /
+// issue_after under hipStreamBeginCapture on the main stream; the side stream joins the capture through the first event wait
+// and is joined back before the capture ends) and replayed with one hipGraphLaunch. An even number of groups returns the
+// buffer parity, so one graph serves every replay; the kernels' iteration numbers (first-unstable bookkeeping) are relative
+// to a device word that the graph itself advances (k_add_int). Where capture is refused — a transport that cannot be
+// captured, an in-process group (its cross-device event waits belong to other captures) — the eager path runs as before.
+constexpr int GRAPH_GROUPS = 4;
+__global__ void k_add_int(int* p, int v) { *p += v; }
+__global__ void k_set_int(int* p, int v) { *p = v; }
+
+
+inline void graph_drop(lbm_ctx* c) {
+    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    c->giters = 0;
+}
+
+// May the next `GRAPH_GROUPS` groups of this context be replayed? (a single context with a device transport on a deep plan
+// that exchanges after every launch, far from the end of the call and from any force output)
+inline bool graph_wanted(const lbm_ctx* c, int remaining, int of, bool transport) {
+    if (!c->use_graph || c->graph_failed || !transport || c->group_n > 1) return false;
+    // RCCL send/recv between REAL peers under stream capture has never run anywhere (this round's boxes have one GPU; the
+    // one-rank communicator sending to itself captures and replays fine): a multi-rank run takes the graph path only when
+    // asked to ("graph" 2) — a refused capture falls back, a hang in an untested collective path would not.
+    if (c->nranks > 1 && c->use_graph < 2) return false;
+    if (!c->deep || deep_depth(c->deep) > GR || c->mid_pair || c->overlap == 2) return false;
+    if (!(face_south(c) || face_north(c))) return false;
+    const int depth = deep_depth(c->deep), iters = GRAPH_GROUPS * depth;
+    if (remaining < iters + 4 * depth + 1) return false;                       // (plan_launch splits the END of a segment differently)
+    if (of > 0 && (c->steps_done % of == 0 || of - c->steps_done % of < iters + 4 * depth + 1)) return false;
+    return true;
+}
+
+// Replay (capturing first, if need be) GRAPH_GROUPS launch groups. Returns the iterations advanced, 0 if the graph path is
+// not available (the caller issues eagerly), < 0 on error.
+template <typename T>
+int replay_groups(lbm_ctx* c, int remaining, int of, bool transport) {
+    const int key[6] = {c->cur, c->overlap, c->deep_halo, c->deep, c->use_nt, c->skip_exchange};
+    if (c->gexec && memcmp(key, c->gkey, sizeof(key)) != 0) graph_drop(c);
+    // everything queued so far, on both streams, precedes the graph: join the side stream into the main one
+    int rc = join_comm(c);
+    if (rc) return rc;
+    if (c->tbase_host != c->steps_done) {      // the graph's launches carry iteration numbers relative to the device word
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, c->d_tbase, c->steps_done);
+        c->tbase_host = c->steps_done;
+    }
+    if (!c->gexec) {
+        struct Saved { int cur, steps_done; long launches_total; bool comm_issued, mid_pair, last_was_pair, ext_split, restored; int e0, e1;
+                       hipEvent_t ev_main, ev_edge, ev_comm; } sv{c->cur, c->steps_done, c->launches_total, c->comm_issued, c->mid_pair,
+                       c->last_was_pair, c->ext_split_pending, c->restored, c->edge_rows[0], c->edge_rows[1], c->ev_main, c->ev_edge, c->ev_comm};
+        auto restore = [&]() {
+            c->cur = sv.cur; c->steps_done = sv.steps_done; c->launches_total = sv.launches_total; c->comm_issued = sv.comm_issued;
+            c->mid_pair = sv.mid_pair; c->last_was_pair = sv.last_was_pair; c->ext_split_pending = sv.ext_split; c->restored = sv.restored;
+            c->edge_rows[0] = sv.e0; c->edge_rows[1] = sv.e1; c->ev_main = sv.ev_main; c->ev_edge = sv.ev_edge; c->ev_comm = sv.ev_comm;
+        };
+        // the capture records and waits for its OWN events, and starts with nothing to wait for (joined above)
+        c->ev_main = c->gev_main; c->ev_edge = c->gev_edge; c->ev_comm = c->gev_comm;
+        c->comm_issued = false; c->ext_split_pending = false;
+        hipGraph_t graph = nullptr;
+        auto note = [&](const char* what, hipError_t e) {
+            if (!c->graph_note[0]) snprintf(c->graph_note, sizeof(c->graph_note), "%s: %s", what, e == hipSuccess ? g_err : hipGetErrorString(e));
+        };
+        hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+        bool ok = e == hipSuccess;
+        if (!ok) note("hipStreamBeginCapture", e);
+        int iters = 0;
+        if (ok) {
+            for (int g = 0; g < GRAPH_GROUPS && ok; ++g) {
+                const int took = advance<T>(c, remaining - iters, of, transport, true);
+                ok = took == deep_depth(c->deep);
+                if (!ok) { char b[64]; snprintf(b, sizeof(b), "group %d took %d iterations", g, took); note(b, hipSuccess); }
+                iters += took > 0 ? took : 0;
+            }
+            if (ok) { ok = join_comm(c) == LBM_OK; if (!ok) note("join", hipSuccess); }   // the side stream rejoins the origin of the capture
+            if (ok) hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, c->stream, c->d_tbase, iters);
+            e = hipStreamEndCapture(c->stream, &graph);
+            if (ok && (e != hipSuccess || !graph)) note("hipStreamEndCapture", e);
+            ok = ok && e == hipSuccess && graph != nullptr;
+        }
+        (void)hipGetLastError();
+        if (ok) { e = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0); ok = e == hipSuccess; if (!ok) note("hipGraphInstantiate", e); }
+        if (graph) (void)hipGraphDestroy(graph);
+        const int cur_after = c->cur;
+        restore();
+        if (ok && cur_after != sv.cur) { ok = false; note("odd number of buffer flips", hipSuccess); }
+        if (!ok) {        // refused: eager from now on
+            graph_drop(c);
+            c->graph_failed = true;
+            (void)hipGetLastError();
+            return 0;
+        }
+        memcpy(c->gkey, key, sizeof(key));
+        c->giters = iters;
+    }
+    HIPCHK(hipGraphLaunch(c->gexec, c->stream));
+    // the host-side state as the eager path would have left it; every stream of the graph was joined into the main one
+    c->steps_done += c->giters;
+    c->tbase_host += c->giters;
+    c->launches_total += GRAPH_GROUPS;
+    c->last_was_pair = true;
+    c->restored = false;
+    c->comm_issued = false;
+    c->ext_split_pending = false;
+    c->mid_pair = false;
+    c->graph_replays++;
+    return c->giters;
 }
 
 // `nsteps` iterations of n strips driven in lockstep by this thread (n == 1: a context on its own, which may talk to
@@ -1105,6 +1276,11 @@ int do_steps(lbm_ctx** cs, int n, int nsteps, int of) {
     } else
     for (int k = 0; k < nsteps;) {
         const int t = c0->steps_done;
+        if (n == 1 && graph_wanted(c0, nsteps - k, of, transport)) {
+            const int took = replay_groups<T>(c0, nsteps - k, of, transport);
+            if (took < 0) return took;
+            if (took > 0) { k += took; launches += GRAPH_GROUPS; continue; }
+        }
         for (int i = 0; i < n; ++i) {
             lbm_ctx* c = cs[i];
             HIPCHK(hipSetDevice(c->device));
@@ -1422,6 +1598,11 @@ int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
     HIPTRY(hipEventCreate(&c->ev_t1));
     // the population buffers are allocated by lbm_initialise (the plan decides their layout)
     HIPTRY(hipMalloc(&c->d_unstable, sizeof(int)));
+    HIPTRY(hipMalloc(&c->d_tbase, sizeof(int)));
+    HIPTRY(hipMemset(c->d_tbase, 0, sizeof(int)));
+    HIPTRY(hipEventCreateWithFlags(&c->gev_main, hipEventDisableTiming));
+    HIPTRY(hipEventCreateWithFlags(&c->gev_edge, hipEventDisableTiming));
+    HIPTRY(hipEventCreateWithFlags(&c->gev_comm, hipEventDisableTiming));
     HIPTRY(hipMalloc(&c->d_solid_count, sizeof(int)));
     HIPTRY(hipMalloc(&c->d_maxbits, sizeof(unsigned long long)));
     HIPTRY(hipMalloc(&c->d_force_now, 3 * sizeof(double)));
@@ -1446,6 +1627,8 @@ void lbm_destroy(lbm_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    // (a graph that captured RCCL operations holds the communicator: ncclCommDestroy waits for it to go away first)
+    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
     if (c->comm) ncclCommDestroy(c->comm);
     for (lbm_ctx* nb : {c->nb_south, c->nb_north}) {  // a destroyed member leaves its group
         if (!nb) continue;
@@ -1459,11 +1642,11 @@ void lbm_destroy(lbm_ctx* c) {
     }
     (void)hipSetDevice(c->device);
     c->pool.reset();
-    void* ptrs[] = {c->buf[0], c->buf[1], c->scratch, c->d_macro, c->d_maxbits, c->d_unstable, c->d_solid_count, c->d_feq,
+    void* ptrs[] = {c->buf[0], c->buf[1], c->scratch, c->d_macro, c->d_maxbits, c->d_unstable, c->d_tbase, c->d_solid_count, c->d_feq,
                     c->d_force_now, c->d_force_log, c->d_halo, c->d_red};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
-    hipEvent_t evs[] = {c->ev_edge, c->ev_comm, c->ev_main, c->ev_t0, c->ev_t1};
+    hipEvent_t evs[] = {c->ev_edge, c->ev_comm, c->ev_main, c->ev_t0, c->ev_t1, c->gev_main, c->gev_edge, c->gev_comm};
     for (hipEvent_t e : evs)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1650,7 +1833,14 @@ int lbm_runtime_versions(int* rccl, int* hip_runtime, int* hip_driver) {
     return LBM_OK;
 }
 
-const char* lbm_strip_schedule(const lbm_ctx* c) { return c ? c->sched_desc : ""; }
+const char* lbm_strip_schedule(const lbm_ctx* c) {
+    if (!c) return "";
+    static thread_local char out[448];
+    if (c->graph_failed) snprintf(out, sizeof(out), "%s; launch groups issued call by call (graph capture given up: %s)", c->sched_desc, c->graph_note);
+    else if (c->graph_replays > 0) snprintf(out, sizeof(out), "%s; %ld hipGraph replays of %d launch groups", c->sched_desc, c->graph_replays, GRAPH_GROUPS);
+    else snprintf(out, sizeof(out), "%s", c->sched_desc);
+    return out;
+}
 
 int lbm_device_memory(int device, unsigned long long* free_bytes, unsigned long long* total_bytes) {
     size_t f = 0, t = 0;
@@ -1846,6 +2036,7 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "deep_halo") { c->deep_halo = (int)value ? 1 : 0; c->deep_pinned = true; }
     else if (k == "skip_exchange") c->skip_exchange = (int)value ? 1 : 0;
     else if (k == "group_threads") c->group_threads = (int)value ? 1 : 0;
+    else if (k == "graph") { if (value < 0 || value > 2) return fail(LBM_ERR_ARG, "graph must be 0, 1 or 2"); c->use_graph = (int)value; }
     else if (k == "loopback") c->loopback = (int)value;   // 0 off, 1 device copies, 2 RCCL self send/recv
     else if (k == "pair_ty") { if (value != 8 && value != 12) return fail(LBM_ERR_ARG, "pair_ty must be 8 or 12"); c->pair_ty = (int)value; }
     else if (k == "tune") c->tune = (int)value ? 1 : 0;
@@ -1879,6 +2070,8 @@ int lbm_last_step_stats(lbm_ctx* c, double* ms_total, int* launches, int* iterat
     if (ms_total) *ms_total = (double)ms;
     return LBM_OK;
 }
+
+long lbm_graph_replays(const lbm_ctx* c) { return c ? c->graph_replays : 0; }
 
 const char* lbm_kernel_name(const lbm_ctx* c) {
     if (!c) return "";

@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
                 }
             }
         }
-        if (bad) atomicMin(a.unstable_t, a.t);
+        if (bad) atomicMin(a.unstable_t, *a.t_base + a.t);
         // ---- levels 2..D: exchange with the neighbouring waves / lanes, then update in place (level D: store)
         auto level = [&]<int L>() {
             T (*xb)[6][LW] = xbuf[L & 1];
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
                 }
                 if (j < R - 1) { p2 = n2; p5 = from_left(n5); p6 = from_right(n6); }   // row j+1 pulls them from this row
             }
-            if (badl) atomicMin(a.unstable_t, a.t + L - 1);
+            if (badl) atomicMin(a.unstable_t, *a.t_base + a.t + L - 1);
         };
         [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (level.template operator()<Ls + 2>(), ...); }(std::make_integer_sequence<int, D - 1>{});
     };

@@ -70,7 +70,9 @@ struct KArgs {
     T tau_inv;         // 1/tau, LBMSolver.h:85
     T u_in;            // inlet velocity
     int* unstable_t;   // device word: first unstable iteration (INT_MAX if none)
-    int t;             // iteration this launch completes (stability bookkeeping only)
+    int t;             // iteration this launch completes, RELATIVE to *t_base (stability bookkeeping only)
+    const int* t_base; // device word: the iteration `t` counts from. A launch replayed from a hipGraph carries a fixed `t`; the
+                       // word is advanced on the device between replays. Read on the (rare) unstable path only.
     int y_lo, y_cnt;   // local rows [y_lo, y_lo + y_cnt) covered by this launch
     int y_lo2, y_cnt2; // optional second range [y_lo2, y_lo2 + y_cnt2) of the same launch (both edge bands of a strip
                        // in one grid); y_cnt2 == 0: none
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(256) k_step_site(const KArgs<T> a) {
             apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
     }
     if (MODE == MODE_STEP) {
-        if (any_unstable(f)) atomicMin(a.unstable_t, a.t);
+        if (any_unstable(f)) atomicMin(a.unstable_t, *a.t_base + a.t);
     }
     if (MODE == MODE_STREAM_ONLY) {
         if (solid) {
@@ -362,7 +364,7 @@ __global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
         for (int i = 0; i < Q; ++i) fv[i][k] = f[i];
     }
     if (MODE == MODE_STEP) {
-        if (bad) atomicMin(a.unstable_t, a.t);
+        if (bad) atomicMin(a.unstable_t, *a.t_base + a.t);
     }
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
@@ -460,7 +462,7 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
 #pragma unroll
         for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
     }
-    if (bad) atomicMin(a.unstable_t, a.t);
+    if (bad) atomicMin(a.unstable_t, *a.t_base + a.t);
     __syncthreads();
     bad = false;
     for (int o = threadIdx.x; o < TX * TY; o += NTH) {         // phase 2: iteration t+1 on the tile
@@ -480,7 +482,7 @@ __global__ void __launch_bounds__(NTH) k_step2_tile(const KArgs<T> a, const K2Ex
         const long c = (long)(y + GR) * a.pitch + a.xoff + x;
         store_pops(a.dst + c, a.plane, f, e.nt != 0);
     }
-    if (bad) atomicMin(a.unstable_t, a.t + 1);
+    if (bad) atomicMin(a.unstable_t, *a.t_base + a.t + 1);
 }
 
 // Three iterations per launch. Same idea one level deeper; the LDS image is reused in place:
@@ -566,7 +568,7 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
 #pragma unroll
             for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
         }
-        if (bad) atomicMin(a.unstable_t, a.t);
+        if (bad) atomicMin(a.unstable_t, *a.t_base + a.t);
         __syncthreads();
         // phase 2: iteration t+1 on region 2, in place
         T g[2][Q];
@@ -622,7 +624,7 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
 #pragma unroll
             for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
         }
-        if (bad) atomicMin(a.unstable_t, a.t + 1);
+        if (bad) atomicMin(a.unstable_t, *a.t_base + a.t + 1);
         __syncthreads();
         bad = false;
         for (int o = threadIdx.x; o < TX * TY; o += NTH) {                    // phase 3: iteration t+2 on the tile
@@ -652,7 +654,7 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
                 store_pops(a.dst + c, a.plane, f, e.nt != 0);
             }
         }
-        if (bad) atomicMin(a.unstable_t, a.t + 2);
+        if (bad) atomicMin(a.unstable_t, *a.t_base + a.t + 2);
     };
     if (lean) run.template operator()<true>();
     else run.template operator()<false>();
@@ -734,7 +736,7 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs
 #pragma unroll
         for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
     }
-    if (bad) atomicMin(a.unstable_t, a.t);
+    if (bad) atomicMin(a.unstable_t, *a.t_base + a.t);
     __syncthreads();
     // levels 2 and 3 on regions 2 and 3, in place: pull into registers, barrier, compute and overwrite, barrier
     auto in_place = [&]<int L>() {
@@ -773,7 +775,7 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs
 #pragma unroll
             for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
         }
-        if (badl) atomicMin(a.unstable_t, a.t + L - 1);
+        if (badl) atomicMin(a.unstable_t, *a.t_base + a.t + L - 1);
         __syncthreads();
     };
     in_place.template operator()<2>();
@@ -804,7 +806,7 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs
         const long c = (long)(y + GR) * a.pitch + a.xoff + x;
         store_pops(a.dst + c, a.plane, f, e.nt != 0);
     }
-    if (bad) atomicMin(a.unstable_t, a.t + 3);
+    if (bad) atomicMin(a.unstable_t, *a.t_base + a.t + 3);
 }
 
 // D iterations per launch (D = 6..8) on a TX x TY tile: k_step4_tile generalised — level 1 from HBM into an LDS image of the
@@ -910,7 +912,7 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
 #pragma unroll
             for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
         }
-        if (bad) atomicMin(a.unstable_t, a.t);
+        if (bad) atomicMin(a.unstable_t, *a.t_base + a.t);
         __syncthreads();
         auto in_place = [&]<int L>() {                                        // level L on region L = region 1 shrunk by L-1 rings
             constexpr int O = L - 1, RW = R1W - 2 * O, RH = R1H - 2 * O, CPT = (RW * RH + NTH - 1) / NTH;
@@ -950,7 +952,7 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
 #pragma unroll
                 for (int i = 0; i < Q; ++i) lds[i][ry][rx] = g[k][i];
             }
-            if (badl) atomicMin(a.unstable_t, a.t + L - 1);
+            if (badl) atomicMin(a.unstable_t, *a.t_base + a.t + L - 1);
             __syncthreads();
         };
         [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (in_place.template operator()<Ls + 2>(), ...); }(std::make_integer_sequence<int, D - 2>{});
@@ -983,7 +985,7 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
                 }
             }
         }
-        if (bad) atomicMin(a.unstable_t, a.t + D - 1);
+        if (bad) atomicMin(a.unstable_t, *a.t_base + a.t + D - 1);
     };
     if (lean) run.template operator()<true>();
     else run.template operator()<false>();

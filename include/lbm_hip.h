@@ -180,7 +180,10 @@ int  lbm_load_state(lbm_ctx* c, const char* path);
  *                 rows of the SAME launch | 2 the exchange overlapped with the interior rows of the NEXT (extended)
  *                 launch; "deep_halo" 1|0 one exchange per two launches (both measured at lbm_initialise when a
  *                 communicator is attached, unless set here),
- *                 "skip_exchange" 1 (diagnostic: no halo traffic, results invalid)
+ *                 "skip_exchange" 1 (diagnostic: no halo traffic, results invalid),
+ *                 "graph" 0|1|2 replay the launch groups of a deep strip plan from a captured hipGraph: 1 (default) where the
+ *                 transport is local to the process, 2 also between the ranks of a communicator (RCCL under capture:
+ *                 exercised with a one-rank communicator only so far)
  *   "timing" 1    record HIP events around each lbm_step call (lbm_last_step_kernel_ms). */
 int  lbm_set_option(lbm_ctx* c, const char* key, long value);
 /* Average device time per step-kernel launch (ms) measured with HIP events on the context's stream around
@@ -189,6 +192,10 @@ int  lbm_last_step_kernel_ms(lbm_ctx* c, double* ms_per_launch);
 /* Same measurement, unreduced: device milliseconds of the last lbm_step call, the step-kernel launches it issued and
  * the iterations it advanced (a fused launch advances two to eight). */
 int  lbm_last_step_stats(lbm_ctx* c, double* ms_total, int* launches, int* iterations);
+/* How many times a captured hipGraph of four launch groups has been replayed for this context so far (a strip with a device
+ * transport on a deep plan replays its launch groups instead of issuing them call by call; option "graph" 0 turns that off;
+ * 0 also where the capture was refused and the eager path runs). No reference counterpart: the reference has no GPU path. */
+long lbm_graph_replays(const lbm_ctx* c);
 const char* lbm_kernel_name(const lbm_ctx* c);
 /* The plan lbm_initialise settled on (layout / kernel / store policy / traversal), for logs. */
 const char* lbm_plan(const lbm_ctx* c);

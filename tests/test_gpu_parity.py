@@ -434,12 +434,15 @@ def test_host_staged_strips_calling_patterns(lbm, plan):
         assert np.array_equal(parts[0][1:129], w_fn[1:129]) and np.array_equal(parts[1][1:129], w_fn[129:257])
 
 
-@pytest.mark.parametrize("precision", ["f64", "f32"])
-def test_tall_strips_take_the_deep_plan_by_rule(lbm, precision):
-    """A measured (tune=1) group whose strips have 64 rows or more runs six iterations per launch on 64x32 regions held in
-    registers (k_stepc_col) with one exchange per launch — chosen by rule from the global grid and the strip count, so that every strip (every rank of a
-    multi-process run) issues the same launch depths — and reproduces the one-domain run bit for bit (fp64 and fp32)."""
-    nx, ny, steps, of = 512, 200, 333, 70
+@pytest.mark.parametrize("precision,ny,expect", [("f64", 200, "6-step 64x16"), ("f32", 200, "6-step 64x16"),
+                                                 ("f64", 600, "6-step 64x32 in registers"), ("f32", 600, "6-step 64x32 in registers")])
+def test_tall_strips_take_the_deep_plan_by_rule(lbm, precision, ny, expect):
+    """A measured (tune=1) group runs six iterations per launch with one exchange per launch where its strips have 64 rows or
+    more — on 64x16 LDS tiles (the shortest launch: such strips are bound by the chain edge band -> exchange -> edge band), from
+    192 rows on 64x32 regions held in registers (k_stepc_col: the highest throughput) — chosen by rule from the global grid and
+    the strip count, so that every strip (every rank of a multi-process run) issues the same launch depths; and reproduces
+    the one-domain run bit for bit (fp64 and fp32)."""
+    nx, steps, of = 512, 333, 70
     kw = dict(inlet_velocity=0.05, cylinder_radius=0.1, precision=precision)
     ftol = 1e-13 if precision == "f64" else 1e-5        # partial force sums are added in a different order
     with lbm.Context(nx, ny, options=PLANS["rowil-site-nt"], **kw) as whole:
@@ -449,7 +452,7 @@ def test_tall_strips_take_the_deep_plan_by_rule(lbm, precision):
     for extra in (dict(), dict(overlap=0), dict(group_threads=0)):
         with lbm.Group(nx, ny, 3, options=extra or None, **kw) as g:
             g.initialise()
-            assert all("6-step 64x32 in registers" in m.plan() for m in g.ctxs), [m.plan() for m in g.ctxs]
+            assert all(expect in m.plan() for m in g.ctxs), [m.plan() for m in g.ctxs]
             g.step(steps, of)
             assert g.first_unstable_step() == -1
             assert np.array_equal(g.populations("f_next"), w_fn)
@@ -459,20 +462,22 @@ def test_tall_strips_take_the_deep_plan_by_rule(lbm, precision):
                 assert abs(fx - wx) <= ftol * max(1.0, abs(wx)) and abs(fy - wy) <= ftol
 
 
-def test_strongly_uneven_strips_under_the_deep_rule(lbm):
-    """The strip rule picks the six-iteration register kernel from ny / strips alone (200 / 3 >= 64), whatever the strips'
-    real heights: strips of 150, 14 and 36 rows — the middle one shorter than one band of tiles, i.e. all edge — must still
-    reproduce the one-domain run bit for bit, with one host thread per strip and with the calling thread issuing for all."""
-    nx, ny, steps, of = 384, 200, 187, 60
+@pytest.mark.parametrize("ny,bounds,expect", [(200, [(0, 150), (150, 14), (164, 36)], "6-step 64x16"),
+                                              (600, [(0, 480), (480, 14), (494, 106)], "6-step 64x32 in registers")])
+def test_strongly_uneven_strips_under_the_deep_rule(lbm, ny, bounds, expect):
+    """The strip rule picks the six-iteration kernel from ny / strips alone, whatever the strips' real heights: a middle strip
+    of 14 rows — shorter than one band of tiles, i.e. all edge — between tall ones must still reproduce the one-domain run bit
+    for bit, with one host thread per strip and with the calling thread issuing for all."""
+    nx, steps, of = 384, 187, 60
     kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
     with lbm.Context(nx, ny, options=PLANS["rowil-site-nt"], **kw) as whole:
         whole.initialise()
         whole.step(steps, of)
         w_fn, w_log = whole.populations("f_next"), whole.drain_force_log()
     for extra in (dict(), dict(group_threads=0, overlap=0)):
-        with lbm.Group(nx, ny, [(0, 150), (150, 14), (164, 36)], options=extra or None, **kw) as g:
+        with lbm.Group(nx, ny, bounds, options=extra or None, **kw) as g:
             g.initialise()
-            assert all("6-step 64x32 in registers" in m.plan() for m in g.ctxs), [m.plan() for m in g.ctxs]
+            assert all(expect in m.plan() for m in g.ctxs), [m.plan() for m in g.ctxs]
             g.step(steps, of)
             assert g.first_unstable_step() == -1
             assert np.array_equal(g.populations("f_next"), w_fn)
@@ -645,6 +650,38 @@ def test_rccl_calls_on_a_one_rank_communicator(lbm):
                 assert np.allclose(ctx.allreduce([1.5, -2.0], "sum"), [1.5, -2.0])      # ncclAllReduce path
     for other in out[1:]:
         assert np.array_equal(out[0][0], other[0]) and out[0][1] == other[1] and out[0][2] == other[2]
+
+
+@pytest.mark.parametrize("loopback", [1, 2])
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_launch_groups_replayed_from_a_graph_match_the_eager_path(lbm, loopback, overlap):
+    """A strip with a device transport on a deep plan replays four launch groups (edge bands, events, exchange, interior rows)
+    per hipGraphLaunch instead of issuing them call by call. Same bits as the eager path — populations, force log across
+    output iterations that cut the replays short, and the FIRST UNSTABLE ITERATION of a run that blows up inside a replayed
+    stretch (the kernels' iteration numbers are relative to a device word the graph advances) — with device copies and with
+    RCCL send/recv to self as the transport, overlapped and serialised."""
+    nx, ny = 512, 160
+    base = dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, loopback=loopback, overlap=overlap)
+    for kw, steps, of in ((dict(inlet_velocity=0.05, cylinder_radius=0.1), 437, 150),
+                          (dict(inlet_velocity=0.05, cylinder_radius=0.1, tau=0.5006), 700, 0)):        # the second one blows up
+        out = []
+        for graph in (0, 1):
+            with lbm.Context(nx, ny, options=dict(base, graph=graph), **kw) as ctx:
+                if loopback == 2:
+                    ctx.comm_init(0, 1, ctx.comm_unique_id())
+                ctx.initialise()
+                ctx.step(steps, of)
+                ctx.step(1, of)
+                ctx.sync()
+                bad = ctx.first_unstable_step()
+                out.append((bad, ctx.populations("f_next") if bad == -1 else None, ctx.drain_force_log() if bad == -1 else None,
+                            ctx.graph_replays()))
+        assert out[0][3] == 0 and out[1][3] >= 2, (out[0][3], out[1][3])
+        assert out[0][0] == out[1][0]
+        if "tau" in kw:
+            assert out[0][0] > 48, out[0][0]          # (it did blow up, and after the first replays)
+        else:
+            assert out[0][0] == -1 and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
 
 
 def test_strip_schedule_is_measured_and_result_invariant(lbm):

@@ -25,6 +25,7 @@ struct Lattice {
     size_t total;
     T *A, *B, *d_feq;
     int* d_unst;
+    int* d_zero;
     hipStream_t s;
     hipEvent_t e0, e1;
     double u_in;
@@ -38,6 +39,8 @@ struct Lattice {
         CK(hipMalloc(&A, (total + 64) * sizeof(T)));
         CK(hipMalloc(&B, (total + 64) * sizeof(T)));
         CK(hipMalloc(&d_unst, sizeof(int)));
+        CK(hipMalloc(&d_zero, sizeof(int)));
+        CK(hipMemset(d_zero, 0, sizeof(int)));
         CK(hipMalloc(&d_feq, Q * sizeof(T)));
         CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -52,7 +55,7 @@ struct Lattice {
         a.plane = plane; a.pitch = pitch; a.xoff = xoff; a.nx = nx; a.ny_loc = ny; a.ny_glob = ny; a.y_start = 0;
         a.cyl_x = (int)(0.2 * nx); a.cyl_y = (int)(0.5 * ny);
         const int r = (int)(0.05 * ny); a.cyl_r2 = (double)(r * r);
-        a.tau_inv = (T)(1.0 / 0.6); a.u_in = (T)u_in; a.unstable_t = d_unst; a.t = depth_t;
+        a.tau_inv = (T)(1.0 / 0.6); a.u_in = (T)u_in; a.unstable_t = d_unst; a.t = depth_t; a.t_base = d_zero;
         return a;
     }
     K2Extra<T> extra() { K2Extra<T> e; e.feq_in = d_feq; e.xcd = 1; e.nt = 1; e.small = (total * sizeof(T) + 4096 < (size_t(1) << 32)) ? 1 : 0; return e; }
