@@ -29,14 +29,24 @@ def main():
         lay = "row-interleaved" if pl.startswith("fixed by options") else pl.split("/")[0]
         ents = [e for e in tj.get(key, []) if e["kernel"].replace(" ", "") == l["config"]["kernel"].replace(" ", "")]
         ents.sort(key=lambda e: (e.get("source", "").split("/")[-2] != name, e.get("layout", "") != lay))
-        t = ents[0]["hbm_bytes_per_launch"] if ents else None
-        fr = t / (r["kernel_ms"] * 1e-3) / 8e12 * (r["iterations_per_launch"] / ents[0]["iterations_per_launch"]) if t else None
-        rows.append(f"| `{name}` | {l['config']['nx']}×{l['config']['ny']} {l['dtype']} | `{l['config']['kernel']}` ({lay}) | {num(l['value'])} | "
-                    f"{r['kernel_ms'] * 1e3:.1f} | {r['iterations_per_launch']:.2f} | {t / 1e6:.1f} | {fr:.2f} | {r['equiv_144B_frac']:.2f} |" if t else
-                    f"| `{name}` | {l['config']['nx']}×{l['config']['ny']} {l['dtype']} | `{l['config']['kernel']}` ({lay}) | {num(l['value'])} | "
-                    f"{r['kernel_ms'] * 1e3:.1f} | {r['iterations_per_launch']:.2f} | - | - | {r['equiv_144B_frac']:.2f} |")
-    print("| config (`alt_*`: plan forced with `--set`) | grid | kernel (layout) | MLUPS | µs / launch (live HIP events) | iterations / launch | HBM MB / launch of that kernel | `frac` | `equiv_144B_frac` |")
-    print("|---|---|---|---|---|---|---|---|---|")
+        e0 = ents[0] if ents else None
+        cells = l["config"]["nx"] * l["config"]["rows_per_gpu"]
+        ipl = r["iterations_per_launch"]
+        secs = r["kernel_ms"] * 1e-3
+        base = f"| `{name}` | {l['config']['nx']}×{l['config']['ny']} {l['dtype']} | `{l['config']['kernel']}` ({lay}) | {num(l['value'])} | {r['kernel_ms'] * 1e3:.1f} | {ipl:.2f} | "
+        if e0:
+            t = e0["hbm_bytes_per_launch"] * ipl / e0["iterations_per_launch"]
+            gbs = t / secs / 1e9
+            rate = {"f64": 256 * 4 * 16 * 2.4e9, "f32": 256 * 4 * 32 * 2.4e9}[l["dtype"]]
+            lane = (e0.get("valu_insts_per_launch") or 0) * 64.0 / (cells * e0["iterations_per_launch"])
+            fv = (cells * ipl / secs) / (rate / lane) if lane else None
+            ldsi = (e0.get("lds_insts_per_launch") or 0) * 64.0 / (cells * e0["iterations_per_launch"])
+            rows.append(base + f"{e0['fetch_bytes_corrected'] / 1e6:.0f} + {e0['write_bytes'] / 1e6:.0f} | {t / (cells * ipl):.1f} | {gbs / 8000:.2f} | "
+                        + (f"{lane:.0f} | {fv:.2f} | {ldsi:.1f} | " if lane else "- | - | - | ") + f"{r.get('frac_144B', r.get('equiv_144B_frac', 0)):.2f} | {cells * ipl / secs / 1e6 / gbs:.1f} |")
+        else:
+            rows.append(base + f"- | - | - | - | - | - | {r.get('frac_144B', r.get('equiv_144B_frac', 0)):.2f} | - |")
+    print("| config (`alt_*`: plan forced with `--set`) | grid | kernel (layout) | MLUPS | µs / launch (live HIP events) | iterations / launch | HBM MB / launch: fetch + write | HBM B / update | `frac_hbm_measured` | VALU lane-instr / update | `frac_valu` | LDS lane-instr / update | `frac_144B` | MLUPS per GB/s |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     print("\n".join(rows))
 
 
