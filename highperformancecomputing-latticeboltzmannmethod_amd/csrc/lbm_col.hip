@@ -1,5 +1,5 @@
-// csrc/lbm_col.hip — the translation unit of k_stepc_col (lbm_kernel_col.hpp): its sixteen instantiations (five / six
-// iterations x store policy x arithmetic x element type) and the launcher lbm_hip.hip calls (lbm_col_api.hpp).
+// csrc/lbm_col.hip — the translation unit(s) of k_stepc_col (lbm_kernel_col.hpp): its 24 instantiations (five / six / seven
+// iterations x store policy x arithmetic x element type, twelve per element type and object file) and the launcher lbm_hip.hip calls (lbm_col_api.hpp).
 #include "lbm_kernel_col.hpp"
 #include "lbm_col_api.hpp"
 
@@ -15,11 +15,14 @@ void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool
                   else hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, true, AR_STRICT>), gridc, blockc, 0, s, a, e); } \
         else { if (contracted) hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, false, AR_CONTRACTED>), gridc, blockc, 0, s, a, e); \
                else hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, false, AR_STRICT>), gridc, blockc, 0, s, a, e); } } while (0)
-    if (depth == 5) LBM_KC(5); else LBM_KC(6);
+    if (depth == 5) LBM_KC(5); else if (depth == 7) LBM_KC(7); else LBM_KC(6);
 #undef LBM_KC
 }
 
-template void launch_col<double>(const KArgs<double>&, const K2Extra<double>&, int, bool, bool, hipStream_t);
-template void launch_col<float>(const KArgs<float>&, const K2Extra<float>&, int, bool, bool, hipStream_t);
+// compiled once per element type (build.py: -DLBM_COL_T=double / float), the two halves side by side
+#ifndef LBM_COL_T
+#error "compile with -DLBM_COL_T=double or -DLBM_COL_T=float"
+#endif
+template void launch_col<LBM_COL_T>(const KArgs<LBM_COL_T>&, const K2Extra<LBM_COL_T>&, int, bool, bool, hipStream_t);
 
 }  // namespace lbmk

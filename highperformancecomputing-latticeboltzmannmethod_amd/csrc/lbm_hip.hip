@@ -290,16 +290,15 @@ void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
 // "deep" plans: shape id -> iterations per launch and tile. 1..3: LDS-image tiles (k_stepd_tile: six / seven iterations on
 // 64x16 tiles, eight on 32x32; what a grid of a single round of blocks picks); 6 / 7: the register-resident column kernel
 // (k_stepc_col, R = 4 rows per thread x 8 waves = a 64 x 32 region per block, two blocks per CU) with five / six iterations —
-// a plan of either uses both depths for what a segment leaves over (seven and eight iterations were measured at 4096x1024
-// fp64 — 160.6 / 154.3 GLUPS against 161.7 — and are not built). Ids 4 / 5 were round 2's 32x16 LDS tiles: retired.
+// a plan of either uses both depths, and on a context without strip faces seven iterations too, for what a segment leaves
+// over (20 = 7 + 7 + 6; at 4096x1024 fp64 seven iterations run at 160.6 GLUPS against 161.7 for six — eight, 154.3, are
+// not built). Ids 4 / 5 were round 2's 32x16 LDS tiles: retired.
 inline bool deep_is_col(int id) { return id == 6 || id == 7; }
 inline bool deep_valid(int id) { return id == 0 || (id >= 1 && id <= 3) || deep_is_col(id); }
 inline int deep_depth(int id) {
     static const int d[8] = {0, 6, 7, 8, 0, 0, 5, 6};
     return id >= 0 && id <= 7 ? d[id] : 0;
 }
-// the other depth of the two-member column family (ids 6/7), 0 if the shape stands alone
-inline int deep_alt_depth(int id) { return id == 6 ? 6 : id == 7 ? 5 : 0; }
 // rows of one band of tiles of a launch of `depth` iterations (the edge bands of a strip are one band each)
 inline int deep_rows(int id, int depth) {
     if (deep_is_col(id)) return col_tile_h(depth);
@@ -571,30 +570,39 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
         if (deep) {
             // `seg` iterations may be fused from here: up to the next force-output iteration (its post-collision state
             // must exist in memory) and the end of the call. A long segment takes the plan's depth; near its end the
-            // cheapest split into launches of the available depths is taken instead (20 = 5 + 5 + 5 + 5 or 6 + 6 + 4 + 4
-            // rather than 6 + 6 + 6 + 2: the two- and one-iteration kernels run at half and a third of the fused rate).
-            // The 32x16 shapes exist with five and with six iterations per launch and the plan may use both.
+            // cheapest split into launches of the available depths is taken instead (20 = 7 + 7 + 6 in registers, 6 + 6 + 4 + 4
+            // on an LDS shape, rather than 6 + 6 + 6 + 2: the two- and one-iteration kernels run at half and a third of the
+            // fused rate).
             const int seg = of > 0 ? std::min(room, of - t % of) : room;
-            const int alt = deep_alt_depth(c->deep);
-            dmax = std::min(any_face ? 3 : 4, std::min(deep, alt ? alt : deep) - 1);
+            // depths the plan's kernel family offers: the register kernel five and six iterations anywhere, seven on a
+            // context without strip faces (a strip's ghost rows go six deep); the LDS shapes their own depth only
+            auto in_family = [&](int d) {
+                if (d == deep) return true;
+                if (!deep_is_col(c->deep)) return false;
+                return d == 5 || d == 6 || (d == 7 && !phys_face);
+            };
+            int fam_min = deep;
+            for (int d = 2; d < deep; ++d) if (in_family(d)) { fam_min = d; break; }
+            dmax = std::min(any_face ? 3 : 4, fam_min - 1);
             if (seg >= 4 * deep) depth = deep;
             else if (seg >= 2) {
                 const double* per_it = c->depth_rel;                             // depth 1..4 relative to the deep kernel
+                constexpr double LAUNCH = 0.25;   // what one more launch costs, in iterations of the deep kernel (kernel boundary + a partly filled last round)
                 double best[64];
                 int first[64];
                 best[0] = 0.0; first[0] = 0;
                 for (int r = 1; r <= seg; ++r) {
                     best[r] = 1e30; first[r] = 1;
                     for (int d = 1; d <= std::min(r, 8); ++d) {
-                        const bool is_deep = (d == deep || d == alt);
-                        if (!is_deep && d > dmax) continue;
-                        const double cst = best[r - d] + (is_deep ? 1.0 : per_it[d - 1]) * d;
-                        if (cst < best[r] - 1e-12 || (is_deep && d == deep && cst < best[r] + 1e-12)) { best[r] = cst; first[r] = d; }
+                        const bool fam = in_family(d);
+                        if (!fam && d > dmax) continue;
+                        const double cst = best[r - d] + (fam ? 1.0 : per_it[d - 1]) * d + LAUNCH;
+                        if (cst < best[r] - 1e-12 || (d == deep && cst < best[r] + 1e-12)) { best[r] = cst; first[r] = d; }
                     }
                 }
                 depth = first[seg];
             }
-            c->deep_now = depth > 1 && (depth == deep || depth == alt);
+            c->deep_now = depth > 1 && in_family(depth);
             dmax = depth;       // (decided: the generic rule below only confirms it)
             deep_plan = true;
         }

@@ -30,11 +30,11 @@ def test_traffic_table_is_wellformed_and_covers_the_baseline_grids():
 
 def test_measured_traffic_lookup_and_labels():
     b = load_bench()
-    t, note = b.measured_traffic(4096, 1024, "f64", "k_step3_tile<double,12,1024,true,true,1>", "row-interleaved")
+    t, note = b.measured_traffic(4096, 1024, "f64", "k_step3_tile<double,12,1024,1>", "row-interleaved")
     assert t and 600e6 < t["hbm_bytes_per_launch"] < 700e6 and "profiles/r0" in note
     t, note = b.measured_traffic(4096, 1024, "f64", "k_step_site<double,0,true,1>")
     assert t is None and "no counter pass" in note
-    assert b.plan_depth_of("k_stepc_col<double,4,8,6,true,1>") == 6 and b.plan_depth_of("k_stepd_tile<double,32,16,5,true,true,1>") == 5
-    assert b.plan_depth_of("k_step3_tile<double,12,1024,true,true,1>") == 3 and b.plan_depth_of("k_step_site<double,0,true,1>") == 1
+    assert b.plan_depth_of("k_stepc_col<double,4,8,6,true,1>") == 6 and b.plan_depth_of("k_stepd_tile<double,32,32,8,1>") == 8
+    assert b.plan_depth_of("k_step3_tile<double,12,1024,1>") == 3 and b.plan_depth_of("k_step_site<double,0,true,1>") == 1
     assert b.CONFIGS[(4096, 1024, "f64", 200.0)] == "configs[2]" and b.CONFIGS[(1024, 256, "f64", 100.0)] == "configs[1]"
     assert b.BYTES_PER_LUP == {"f64": 144, "f32": 72} and b.HBM_PEAK_GBS == 8000.0

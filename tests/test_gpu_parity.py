@@ -554,14 +554,15 @@ def test_checkpoint_restart_is_bit_exact(lbm, tmp_path):
 
 
 @pytest.mark.parametrize("plan,steps,of,trailing,launches", [
-    ("rowil-col5-nt", 20, 0, 1, 4),         # 5+5+5+5
+    ("rowil-col5-nt", 20, 0, 1, 3),         # 7+7+6: a whole domain may fuse seven (a strip's ghost rows go six deep)
     ("rowil-deep6-nt", 20, 0, 1, 4),        # 6+6+4+4 rather than 6+6+6+2
     ("rowil-deep8-nt", 19, 0, 1, 3),        # 8+8+3
-    ("rowil-col5-nt", 20, 0, 0, 5),         # 5+5+5+4 and the single last iteration of a call that may be read back
+    ("rowil-col5-nt", 20, 0, 0, 4),         # 7+7+5 and the single last iteration of a call that may be read back
     ("rowil-col5-nt", 24, 10, 1, 5),        # force outputs at 10 and 20 end the fused segments: 5+5 | 5+5 | 4
     ("rowil-fuse3-12-nt-xcd", 20, 0, 1, 6), # 4+4+3+3+3+3
-    ("rowil-col5-nt", 22, 0, 1, 4),         # 6+6+5+5: the register-column family uses both of its depths too
-    ("planar-col6-alt", 20, 0, 0, 5),       # 5+5+5+4 and the single last iteration
+    ("rowil-col5-nt", 22, 0, 1, 4),         # 6+6+5+5 / 7+5+5+5: the register family splits without a slow tail
+    ("planar-col6-alt", 20, 0, 0, 4),       # 7+7+5 and the single last iteration
+    ("planar-col6-alt", 38, 0, 1, 6),       # 6+6+6+6+7+7 rather than six sixes and a two
 ])
 def test_a_call_is_split_into_full_rate_launches(lbm, plan, steps, of, trailing, launches):
     """plan_launch: the iterations of a call (between force outputs) are split into the cheapest sequence of the depths the
