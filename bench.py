@@ -277,6 +277,9 @@ def main():
     bad = ctx.first_unstable_step()
     if bad != -1:
         sys.exit(f"simulation unstable at timestep {bad}: result invalid")
+    # what ran in the timed region (the parity pass below initialises the context again)
+    kernel, plan_used, schedule_used = ctx.kernel_name(), ctx.plan(), ctx.strip_schedule()
+    roof = roofline_of(lbm, ctx, nx, local_ny, args.precision, kernel_ms, launches, iterations, args.steps) if rank == 0 else None
     parity = None
     if world > 1:
         # what the halo traffic costs: the same launches with the exchange skipped (diagnostic pass, results discarded)
@@ -320,8 +323,6 @@ def main():
         mlups = cells * args.steps / dt / 1e6
         hr = lbm.Context.HALO_ROWS
         cfg_name = CONFIGS.get((nx, ny_total, args.precision, float(args.re)))
-        kernel = ctx.kernel_name()
-        roof = roofline_of(lbm, ctx, nx, local_ny, args.precision, kernel_ms, launches, iterations, args.steps)
         line = {
             "metric": f"MLUPS ({'fp64' if args.precision == 'f64' else 'fp32'})", "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
@@ -334,8 +335,8 @@ def main():
                                       "1e-10 of the reference)" if args.arith == "contracted" else
                                       "strict IEEE, operation by operation (populations bit-identical to the CPU oracle)"),
                        "halo": "none" if world == 1 else f"RCCL send/recv of {hr} edge rows x 9 populations per face (one contiguous message "
-                                                          f"of {hr * 9} sub-rows); schedule: {ctx.strip_schedule()}",
-                       "kernel": kernel, "plan": ctx.plan(), "build_id": lbm.build_id(),
+                                                          f"of {hr * 9} sub-rows); schedule: {schedule_used}",
+                       "kernel": kernel, "plan": plan_used, "build_id": lbm.build_id(),
                        "runtime": {"rccl": versions["rccl"], "hip_runtime": versions["hip_runtime"], "hip_driver": versions["hip_driver"],
                                    "torch_loaded": torch is not None}},
             "roofline": roof,
@@ -345,7 +346,7 @@ def main():
                                  "ms_per_step": round(dt_sus / sus_steps * 1e3, 5),
                                  "note": "a second, longer window of the same context, same fences; `value` above is the contract's K-step window"}
         if world > 1:
-            line["strips"] = {"nranks": world, "schedule": ctx.strip_schedule(),
+            line["strips"] = {"nranks": world, "schedule": schedule_used,
                               "ms_per_step_compute_only": round(compute_only_ms, 5),
                               "ms_per_step_exchange_exposed": round(dt / args.steps * 1e3 - compute_only_ms, 5)}
             line["strips"].update(parity)
@@ -394,6 +395,28 @@ def single_precision_variant(lbm, device, args):
         return {"error": str(e)[:200]}
 
 
+def row_checksums(populations):
+    """Exact per-row checksum of a [rows, nx+2, 9] float64 array: the sum of the bit patterns modulo 2**64."""
+    import numpy as np
+    a = np.ascontiguousarray(populations, dtype=np.float64)
+    return a.view(np.uint64).reshape(a.shape[0], -1).sum(axis=1, dtype=np.uint64)
+
+
+def compare_row_checksums(gathered, whole_sums):
+    """'bit-equal', or where the strips' rows first differ from the whole-grid run. gathered: one dict per rank with `rank`,
+    `y_start`, `rows` and `sums` (the strip's per-row checksums)."""
+    import numpy as np
+    for g in sorted(gathered, key=lambda g: g["rank"]):
+        got = np.array(g["sums"], dtype=np.uint64)
+        ref = np.asarray(whole_sums, dtype=np.uint64)[g["y_start"]:g["y_start"] + g["rows"]]
+        if got.shape != ref.shape:
+            return f"MISMATCH: rank {g['rank']} reports {got.shape[0]} rows, the whole grid has {ref.shape[0]} there"
+        diff = np.nonzero(got != ref)[0]
+        if diff.size:
+            return f"MISMATCH: rank {g['rank']} first differs at global row {g['y_start'] + int(diff[0])} ({diff.size} of {g['rows']} rows)"
+    return "bit-equal"
+
+
 def strip_parity(lbm, ctx, dist, rank, world, nx, ny_total, local_ny, u_in, args, device):
     """Outside the timed region: a SECOND short run from iteration 0 on the strips (same communicator, same measured plan and
     schedule: lbm_initialise again), whose post-collision populations are compared row by row, bit for bit, with a one-GPU
@@ -406,8 +429,7 @@ def strip_parity(lbm, ctx, dist, rank, world, nx, ny_total, local_ny, u_in, args
     ctx.initialise()                         # collective (the strip schedule is re-measured): every rank is here
     ctx.step(its, 0)
     ctx.sync()
-    fn = ctx.populations("f_next")[1:-1]    # (local_ny, nx+2, 9): the strip's own rows, ghost columns included
-    sums = np.ascontiguousarray(fn).view(np.uint64).reshape(local_ny, -1).sum(axis=1, dtype=np.uint64)      # exact per-row checksum of the bit patterns
+    sums = row_checksums(ctx.populations("f_next")[1:-1])    # (local_ny, nx+2, 9): the strip's own rows, ghost columns included
     info = dict(rank=rank, y_start=rank * local_ny, rows=local_ny, plan=ctx.plan(), schedule=ctx.strip_schedule(),
                 kernel=ctx.kernel_name(), unstable=ctx.first_unstable_step(), sums=sums.tolist())
     gathered = [None] * world
@@ -418,17 +440,9 @@ def strip_parity(lbm, ctx, dist, rank, world, nx, ny_total, local_ny, u_in, args
                      options=dict(arith=1 if args.arith == "contracted" else 0)) as whole:
         whole.initialise()
         whole.step(its, 0)
-        wf = whole.populations("f_next")[1:-1]
-        wsums = np.ascontiguousarray(wf).view(np.uint64).reshape(ny_total, -1).sum(axis=1, dtype=np.uint64)
+        wsums = row_checksums(whole.populations("f_next")[1:-1])
         wplan = whole.plan()
-    verdict = "bit-equal"
-    for g in sorted(gathered, key=lambda g: g["rank"]):
-        got = np.array(g["sums"], dtype=np.uint64)
-        ref = wsums[g["y_start"]:g["y_start"] + g["rows"]]
-        diff = np.nonzero(got != ref)[0]
-        if diff.size:
-            verdict = f"MISMATCH: rank {g['rank']} first differs at global row {g['y_start'] + int(diff[0])} ({diff.size} of {g['rows']} rows)"
-            break
+    verdict = compare_row_checksums(gathered, wsums)
     return {"parity": verdict,
             "parity_basis": f"{its} iterations from initialise on the {world} strips vs one whole-grid context on rank 0's GPU ({wplan}); "
                             f"per-row checksums of the f_next bit patterns, gathered over gloo",

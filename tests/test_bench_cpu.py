@@ -38,3 +38,42 @@ def test_measured_traffic_lookup_and_labels():
     assert b.plan_depth_of("k_step3_tile<double,12,1024,1>") == 3 and b.plan_depth_of("k_step_site<double,0,true,1>") == 1
     assert b.CONFIGS[(4096, 1024, "f64", 200.0)] == "configs[2]" and b.CONFIGS[(1024, 256, "f64", 100.0)] == "configs[1]"
     assert b.BYTES_PER_LUP == {"f64": 144, "f32": 72} and b.HBM_PEAK_GBS == 8000.0
+
+
+def test_strip_parity_checksums():
+    """bench.py --gpus N compares per-row checksums of the strips' f_next bit patterns with a whole-grid run: the comparison
+    says bit-equal only for bit-equal rows (a sign flip of a zero counts) and names the first differing global row."""
+    import numpy as np
+    b = load_bench()
+    rng = np.random.default_rng(7)
+    whole = rng.standard_normal((12, 10, 9))
+    ws = b.row_checksums(whole)
+    parts = [dict(rank=1, y_start=5, rows=7, sums=b.row_checksums(whole[5:12]).tolist()),
+             dict(rank=0, y_start=0, rows=5, sums=b.row_checksums(whole[0:5]).tolist())]
+    assert b.compare_row_checksums(parts, ws) == "bit-equal"
+    bad = whole.copy()
+    bad[8, 3, 2] = np.nextafter(bad[8, 3, 2], 10.0)
+    parts[0]["sums"] = b.row_checksums(bad[5:12]).tolist()
+    assert b.compare_row_checksums(parts, ws).startswith("MISMATCH: rank 1 first differs at global row 8 (1 of 7 rows)")
+    z = np.zeros((2, 4, 9))
+    zs = b.row_checksums(z)
+    z[1, 0, 0] = -0.0
+    assert b.compare_row_checksums([dict(rank=0, y_start=0, rows=2, sums=b.row_checksums(z).tolist())], zs).startswith("MISMATCH")
+
+
+def test_roofline_object_from_a_committed_pass():
+    """roofline_of on the headline grid with the register kernel: the contract's frac is the 144 B figure (above 1 for a fused
+    launch), the measured HBM and vector-issue fractions come from profiles/traffic.json and stay below 1, bound = the larger."""
+    b = load_bench()
+
+    class Ctx:
+        def kernel_name(self): return "k_stepc_col<double,4,8,6,false,1>"
+        def plan(self): return "row-interleaved/6-step 64x32 in registers/xcd (fastest of 27 measured, 26.9 us/iteration)"
+    r = b.roofline_of(None, Ctx(), 4096, 1024, "f64", 0.160, 1000, 6000, 6000)
+    assert r["iterations_per_launch"] == 6.0 and r["algorithmic_bytes_per_launch"] == 4096 * 1024 * 144 * 6
+    assert abs(r["frac"] - 4096 * 1024 * 144 * 6 / 0.160e-3 / 8e12) < 1e-3 and r["frac"] == r["frac_144B"] > 2.0
+    assert r["traffic"] and 0.3 < r["frac_hbm_measured"] < 1.0 and 0.2 < r["frac_valu"] < 1.0
+    assert r["bound"] == ("valu" if r["frac_valu"] > r["frac_hbm_measured"] else "hbm")
+    assert abs(r["mlups_per_gbs"] - 1000.0 / r["hbm_bytes_per_update"]) < 0.05
+    r5 = b.roofline_of(None, Ctx(), 4096, 1024, "f64", 0.140, 4, 20, 20)      # a 20-step call: mixed depths, traffic scaled
+    assert abs(r5["traffic"] / r["traffic"] - 5.0 / 6.0) < 1e-6 and "scaled" in r5["traffic_source"]
