@@ -155,9 +155,6 @@ struct lbm_ctx {
     int xcd = 0;         // fused kernels: remap blocks so that each XCD walks a contiguous run of tiles
     bool deep_now = false;   // the launch being issued is the plan's deep launch (set by plan_launch)
     int deep = 0;        // 1..3: k_stepd_tile shape (6/7/8 iterations per launch on an LDS-filling tile); 6/7: k_stepc_col (registers)
-    int edge_deep = 0;   // strips on the register kernel: shape id of the EDGE-BAND launches (1: the 64x16 LDS tile of one-cell threads,
-                         // the shortest launch — the chain edge band -> exchange -> edge band is what a short strip waits for);
-                         // 0: the plan's own kernel. Same depth, same bits; the interior rows stay on the plan's kernel.
     int arith = 0;       // collision arithmetic: 0 strict IEEE op-by-op (bit-identical to the oracle), 1 contracted (FMA +
                          // one reciprocal, as the reference's -ffast-math -mfma build permits); see lbm_kernels.hpp Arith
     int num_cus = 256;   // compute units of the device (what counts as a small grid: one round of blocks)
@@ -314,8 +311,8 @@ inline const char* deep_tile(int id) {
 
 // A fused kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt): iterations a.t .. a.t + depth - 1 (depth 2..8).
 template <typename T>
-void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s, int shape_override = 0) {
-    const int shape = shape_override ? shape_override : c->deep;
+void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s) {
+    const int shape = c->deep;
     K2Extra<T> e;
     e.feq_in = static_cast<const T*>(c->d_feq);
     e.small = ((c->total + (size_t)c->pitch) * c->esize + 1024 < (size_t(1) << 32)) ? 1 : 0;   // 32-bit byte offsets (+ one row of slack)
@@ -542,8 +539,8 @@ inline bool face_south(const lbm_ctx* c) { return c->p.y_start > 0 || c->loopbac
 inline bool face_north(const lbm_ctx* c) { return c->p.y_start + c->nyl < c->p.ny || c->loopback; }
 
 template <typename T>
-void launch_depth(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s, int shape_override = 0) {
-    if (depth > 1) launch_fused_rows<T>(c, a, depth, s, shape_override);
+void launch_depth(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s) {
+    if (depth > 1) launch_fused_rows<T>(c, a, depth, s);
     else launch_rows<T, MODE_STEP>(c, a, s);
 }
 
@@ -701,10 +698,10 @@ int issue_before(lbm_ctx* c, const Launch& L) {
         return LBM_OK;
     }
     const bool has_s = face_south(c), has_n = face_north(c);
-    // the edge bands may run on a different shape of the same depth (edge_deep): then they are one band of THAT shape high
-    const int eshape = (c->deep_now && c->edge_deep && deep_depth(c->edge_deep) == L.depth) ? c->edge_deep : 0;
-    const int EB = eshape ? deep_rows(eshape, L.depth) : E;
-    int e0 = has_s ? EB : 0, e1 = has_n ? EB : 0;
+    // (edge bands on the 64x16 LDS tile of one-cell threads with the interior in registers — the shortest edge launch — were
+    // measured: one rank of eight / four / two 8.70 / 11.48 / 17.61 us per iteration against 8.63 / 11.38 / 17.39 for the
+    // register kernel throughout: the interior blocks share the CUs with the edge blocks either way. Not kept.)
+    int e0 = has_s ? E : 0, e1 = has_n ? E : 0;
     if (e0 + e1 >= c->nyl) { e0 = c->nyl; e1 = 0; }          // short strip: everything is edge
     HIPCHK(hipEventRecord(c->ev_main, c->stream));
     HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_main, 0));
@@ -714,7 +711,7 @@ int issue_before(lbm_ctx* c, const Launch& L) {
     a.reverse = 0;
     a.y_lo = 0; a.y_cnt = e0; a.y_lo2 = c->nyl - e1; a.y_cnt2 = e1;
     if (e0 == 0) { a.y_lo = a.y_lo2; a.y_cnt = e1; a.y_cnt2 = 0; }
-    launch_depth<T>(c, a, L.depth, c->comm_stream, eshape);
+    launch_depth<T>(c, a, L.depth, c->comm_stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_edge, c->comm_stream));
     c->edge_rows[0] = e0; c->edge_rows[1] = e1;
@@ -1162,7 +1159,7 @@ inline bool graph_wanted(const lbm_ctx* c, int remaining, int of, bool transport
 // not available (the caller issues eagerly), < 0 on error.
 template <typename T>
 int replay_groups(lbm_ctx* c, int remaining, int of, bool transport) {
-    const int key[6] = {c->cur, c->overlap, c->deep_halo, c->deep + 16 * c->edge_deep, c->use_nt, c->skip_exchange};
+    const int key[6] = {c->cur, c->overlap, c->deep_halo, c->deep, c->use_nt, c->skip_exchange};
     if (c->gexec && memcmp(key, c->gkey, sizeof(key)) != 0) graph_drop(c);
     // everything queued so far, on both streams, precedes the graph: join the side stream into the main one
     int rc = join_comm(c);
@@ -2054,7 +2051,6 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "deep_halo") { c->deep_halo = (int)value ? 1 : 0; c->deep_pinned = true; }
     else if (k == "skip_exchange") c->skip_exchange = (int)value ? 1 : 0;
     else if (k == "group_threads") c->group_threads = (int)value ? 1 : 0;
-    else if (k == "edge_deep") { if (value != 0 && value != 1) return fail(LBM_ERR_ARG, "edge_deep must be 0 or 1"); c->edge_deep = (int)value; }
     else if (k == "graph") { if (value < 0 || value > 2) return fail(LBM_ERR_ARG, "graph must be 0, 1 or 2"); c->use_graph = (int)value; }
     else if (k == "loopback") c->loopback = (int)value;   // 0 off, 1 device copies, 2 RCCL self send/recv
     else if (k == "pair_ty") { if (value != 8 && value != 12) return fail(LBM_ERR_ARG, "pair_ty must be 8 or 12"); c->pair_ty = (int)value; }

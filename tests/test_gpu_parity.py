@@ -51,8 +51,6 @@ PLANS = {
     # values per wave and level; round 3's production kernel — what a large grid's measurement and the strip rule pick)
     "rowil-col5-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=6),
     "planar-col6-alt": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, pair_ty=8, xcd=1, deep=7),
-    # ... with the edge bands of a strip on the 64x16 LDS tile of one-cell threads (the shortest launch), the interior in registers
-    "rowil-col6-ldsedge": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, edge_deep=1),
     # contracted collision arithmetic (option "arith" 1: FMA + one reciprocal, what the reference's -ffast-math -mfma build
     # permits): not bit-identical to the strict oracle, held to the north-star tolerance 1e-10 like every other plan
     "fast-auto": dict(arith=1),
@@ -364,7 +362,7 @@ def test_overlap_choreography_with_loopback_halo(lbm, pair):
 
 @pytest.mark.parametrize("overlap,deep", [(1, 1), (0, 1), (1, 0), (0, 0), (2, 1), (2, 0)])
 @pytest.mark.parametrize("plan", ["rowil-fuse3-12-nt-xcd", "rowil-pair12-alt", "rowil-site-nt", "fast-rowil-fuse3-12-xcd",
-                                  "rowil-deep6-nt", "rowil-col5-nt", "fast-rowil-col6", "rowil-col6-ldsedge"])
+                                  "rowil-deep6-nt", "rowil-col5-nt", "fast-rowil-col6"])
 def test_group_of_strips_on_one_device_matches_single_domain_bitwise(lbm, plan, overlap, deep):
     """In-process strips (lbm_group_*, the transport `lbm_solver --gpus N` uses) with the production choreography: edge
     bands on the side stream, every strip PULLING its neighbours' edge rows with exactly the pointers / offsets / counts
@@ -665,8 +663,7 @@ def test_launch_groups_replayed_from_a_graph_match_the_eager_path(lbm, loopback,
     stretch (the kernels' iteration numbers are relative to a device word the graph advances) — with device copies and with
     RCCL send/recv to self as the transport, overlapped and serialised."""
     nx, ny = 512, 160
-    base = dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, loopback=loopback, overlap=overlap,
-                edge_deep=(loopback + overlap) % 2)        # (half of the cases with the edge bands on the LDS tile)
+    base = dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, loopback=loopback, overlap=overlap)
     for kw, steps, of in ((dict(inlet_velocity=0.05, cylinder_radius=0.1), 437, 150),
                           (dict(inlet_velocity=0.05, cylinder_radius=0.1, tau=0.5006), 700, 0)):        # the second one blows up
         out = []

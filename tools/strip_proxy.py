@@ -25,7 +25,6 @@ for n in [int(v) for v in sys.argv[1:]] or (1, 2, 4, 8):
                        ("no-exchange deep", dict(deep)),
                        ("rccl-self deep ovl", dict(deep, loopback=2, overlap=1)),
                        ("rccl-self deep ser", dict(deep, loopback=2, overlap=0)),
-                       ("rccl-self deep+lds-edges ovl", dict(deep, loopback=2, overlap=1, edge_deep=1)),
                        ("rccl-self TUNED", dict(arith=1, trailing_pair=1, loopback=2)),
                        ("rccl-self ovl+deep", dict(base, loopback=2, overlap=1, deep_halo=1)),
                        ("rccl-self ser+deep", dict(base, loopback=2, overlap=0, deep_halo=1)),
