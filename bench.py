@@ -218,7 +218,8 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
     ndev = lbm.device_count()
     device = local_rank % ndev          # (a launcher may expose one device per rank)
 
@@ -425,24 +426,36 @@ def strip_parity(lbm, ctx, dist, rank, world, nx, ny_total, local_ny, u_in, args
     reference's Grid::exchange_ghost_cells, LBMGrid.h:249-283) by itself."""
     import numpy as np
     its = 24
-    ctx.set_option("trailing_pair", 0)      # the call ends on a single iteration: f_next can be read back
-    ctx.initialise()                         # collective (the strip schedule is re-measured): every rank is here
-    ctx.step(its, 0)
-    ctx.sync()
-    sums = row_checksums(ctx.populations("f_next")[1:-1])    # (local_ny, nx+2, 9): the strip's own rows, ghost columns included
-    info = dict(rank=rank, y_start=rank * local_ny, rows=local_ny, plan=ctx.plan(), schedule=ctx.strip_schedule(),
-                kernel=ctx.kernel_name(), unstable=ctx.first_unstable_step(), sums=sums.tolist())
+    try:      # (whatever goes wrong on a rank, it still takes part in the gather below: nobody is left waiting)
+        ctx.set_option("trailing_pair", 0)      # the call ends on a single iteration: f_next can be read back
+        ctx.initialise()                         # collective (the strip schedule is re-measured): every rank is here
+        ctx.step(its, 0)
+        ctx.sync()
+        sums = row_checksums(ctx.populations("f_next")[1:-1])    # (local_ny, nx+2, 9): the strip's own rows, ghost columns included
+        info = dict(rank=rank, y_start=rank * local_ny, rows=local_ny, plan=ctx.plan(), schedule=ctx.strip_schedule(),
+                    kernel=ctx.kernel_name(), unstable=ctx.first_unstable_step(), sums=sums.tolist())
+    except Exception as e:
+        info = dict(rank=rank, y_start=rank * local_ny, rows=local_ny, plan="", schedule="", kernel="", unstable=None, sums=None,
+                    error=f"{type(e).__name__}: {e}"[:300])
     gathered = [None] * world
     dist.all_gather_object(gathered, info)
     if rank != 0:
         return {}
-    with lbm.Context(nx, ny_total, tau=0.6, inlet_velocity=u_in, precision=args.precision, device=device,
-                     options=dict(arith=1 if args.arith == "contracted" else 0)) as whole:
-        whole.initialise()
-        whole.step(its, 0)
-        wsums = row_checksums(whole.populations("f_next")[1:-1])
-        wplan = whole.plan()
-    verdict = compare_row_checksums(gathered, wsums)
+    errors = [f"rank {g['rank']}: {g['error']}" for g in gathered if g.get("error")]
+    wplan = ""
+    if errors:
+        verdict = "unavailable (" + "; ".join(errors) + ")"
+    else:
+        try:
+            with lbm.Context(nx, ny_total, tau=0.6, inlet_velocity=u_in, precision=args.precision, device=device,
+                             options=dict(arith=1 if args.arith == "contracted" else 0)) as whole:
+                whole.initialise()
+                whole.step(its, 0)
+                wsums = row_checksums(whole.populations("f_next")[1:-1])
+                wplan = whole.plan()
+            verdict = compare_row_checksums(gathered, wsums)
+        except Exception as e:
+            verdict = f"unavailable (whole-grid run on rank 0: {type(e).__name__}: {e})"[:400]
     return {"parity": verdict,
             "parity_basis": f"{its} iterations from initialise on the {world} strips vs one whole-grid context on rank 0's GPU ({wplan}); "
                             f"per-row checksums of the f_next bit patterns, gathered over gloo",

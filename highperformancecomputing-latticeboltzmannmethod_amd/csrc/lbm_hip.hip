@@ -563,7 +563,8 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
         int dmax = std::min(c->fuse, any_face ? 3 : 4);  // (four: k_step4_tile, no faces)
         // a deep plan: D iterations while D fit, then the four-/three-/two-iteration tile kernels for what is left
         // (a strip with faces: its ghost rows go GR deep and are refreshed after every launch, so a deep launch of up to GR
-        // iterations works there too — the 32x16 and 64x16 shapes with five / six iterations, not the seven / eight ones)
+        // iterations works there too — the register kernel with five / six iterations and the 64x16 LDS shape with six, not the
+        // seven / eight ones)
         // Whether the faces are EXCHANGED in this call (strip_logic) or not (the plan probe), a context whose rows end at an
         // internal face has GR rows beyond them and no more: the seven- / eight-iteration shapes would read past the frame.
         const bool phys_face = face_south(c) || face_north(c);

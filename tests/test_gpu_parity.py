@@ -862,7 +862,7 @@ def test_c5_grid_16384x4096_fp32_single_gpu(lbm):
     cells is out of reach, so at full size the checks are the size-independent properties: geometry (130 721 solid
     cells), stability over 300 iterations, fp32 against this library's fp64 path on the same full-size grid at a
     stated, measured tolerance, run-to-run determinism,
-    plan-to-plan bit-equality (measured plan vs tile kernel vs sliding kernel vs one launch per iteration) and
+    plan-to-plan bit-equality (measured plan vs LDS tiles vs the register kernel vs one launch per iteration) and
     decomposition invariance (8 in-process strips with the production exchange choreography == the whole domain)."""
     nx, ny, steps = 16384, 4096, 300
     kw = dict(inlet_velocity=0.01627604, precision="f32")

@@ -1,6 +1,6 @@
 """Seeded random sweep of the parameter space: grid sizes (ragged, tiny, one tile column, many), tau, inlet velocity,
 cylinder position/radius (inside, on the inlet, on a wall, on a corner, absent, covering the outlet), fusion depth,
-kernel family (tile / sliding window / deep tile), layout, store policy, collision arithmetic and — where the grid is tall enough —
+kernel family (LDS tile / deep LDS tile / register column), layout, store policy, collision arithmetic and — where the grid is tall enough —
 an in-process group of strips with a random exchange schedule. Every case is compared with the CPU oracle: strict
 arithmetic populations bit for bit, contracted arithmetic within 1e-10; rho/u and forces to 1e-10 either way.
 """
