@@ -233,6 +233,13 @@ def test_contracted_arithmetic_is_plan_independent(lbm):
         assert np.array_equal(out[0][0], other[0]) and out[0][2] == other[2]
         for u, v in zip(out[0][1], other[1]):
             assert np.array_equal(u, v)
+    # ... and calls whose length makes the register family use all of its depths (20 = 7+7+6, 17 = 6+6+5, 5, 38 = 6x4+7+7)
+    with lbm.Context(nx, ny, options=dict(PLANS["fast-rowil-col6"], trailing_pair=1), **kw) as ctx:
+        ctx.initialise()
+        for n in (20, 17, 5, 38, 60, 60, 39):
+            ctx.step(n, of)
+        ctx.step(1, of)
+        assert ctx.steps_done == steps and np.array_equal(ctx.populations("f_next"), out[0][0]) and ctx.drain_force_log() == out[0][2]
     ctxs, _ = _run_strips(lbm, nx, ny, [(0, 40), (40, 13), (53, 37)], steps, of, pairs=True,
                           plans=["fast-rowil-fuse3-12-xcd", "fast-planar-pair8", "fast-rowil-col6"], **kw)
     assert np.array_equal(np.concatenate([c.populations("f_next")[1:-1] for c in ctxs], axis=0), out[0][0][1:-1])
