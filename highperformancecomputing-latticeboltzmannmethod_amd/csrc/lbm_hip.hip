@@ -822,7 +822,7 @@ inline void apply_plan(lbm_ctx* c, const Plan& pl) {
 }
 
 template <typename T>
-int time_plan(lbm_ctx* c, float* ms_out) {
+int time_plan(lbm_ctx* c, float* ms_out, int window = 36) {
     int rc = init_state<T>(c);
     if (rc) return rc;
     auto run = [&](int n) -> int {
@@ -839,10 +839,10 @@ int time_plan(lbm_ctx* c, float* ms_out) {
     rc = run(12);
     if (rc) return rc;
     *ms_out = 1e30f;
-    for (int rep = 0; rep < 2; ++rep) {      // the faster of two windows of 36 iterations (a dozen fused launches each)
+    for (int rep = 0; rep < 2; ++rep) {      // the faster of two windows of `window` iterations (36: six to a dozen fused launches each)
         const int t0 = c->steps_done;
         HIPCHK(hipEventRecord(c->ev_t0, c->stream));
-        rc = run(36);
+        rc = run(window);
         if (rc) return rc;
         HIPCHK(hipEventRecord(c->ev_t1, c->stream));
         HIPCHK(hipEventSynchronize(c->ev_t1));
@@ -962,9 +962,11 @@ int choose_plan(lbm_ctx* c) {
         for (Kept& t : top) {
             apply_plan(c, cand[(size_t)t.k]);
             c->buf[0] = t.buf[0]; c->buf[1] = t.buf[1];
+            // (longer windows: the finalists are often 2-3 % apart — store policy, walk direction — and the alternating walk
+            // only shows what it gains from the Infinity Cache once a few launches have gone both ways)
             float a = 0.f, b = 0.f;
-            int rc = time_plan<T>(c, &a);
-            if (!rc) rc = time_plan<T>(c, &b);
+            int rc = time_plan<T>(c, &a, 120);
+            if (!rc) rc = time_plan<T>(c, &b, 120);
             c->buf[0] = c->buf[1] = nullptr;
             if (rc) { drop_all(); return rc; }
             t.ms = std::min(a, b);
