@@ -75,6 +75,27 @@ def cases(n=36, seed=20260104):
         if strips > 1:
             opts.update(layout=1, overlap=int(rng.integers(0, 3)), deep_halo=int(rng.integers(0, 2)))
         out.append((k, nx, ny, tau, u, cx, cy, cr, steps, of, opts, strips))
+    # round 3: the register-column kernel (five / six, on whole domains seven iterations per launch) on grids from less than
+    # one region to several tiles per direction, alone and under the strip choreography (edge bands, exchange, interior rows)
+    for k in range(2 * n + 40, 2 * n + 100):
+        nx = int(rng.choice([rng.integers(2, 60), rng.integers(60, 200), rng.integers(200, 700), 54, 55, 56, 57, 108, 112, 64, 128]))
+        ny = int(rng.choice([rng.integers(2, 24), rng.integers(24, 80), rng.integers(80, 160), 22, 23, 24, 25, 44, 48, 32, 64]))
+        tau = float(rng.uniform(0.56, 1.2))
+        u = float(rng.uniform(0.005, 0.09))
+        cyl = rng.integers(0, 6)
+        cx, cy, cr = [(0.2, 0.5, 0.05), (-1.0, 0.5, 0.0), (0.0, 0.5, 0.15), (0.5, 0.0, 0.2), (0.0, 0.0, 0.3), (0.98, 0.5, 0.25)][cyl]
+        cx += float(rng.uniform(-0.02, 0.02)) if cyl not in (1,) else 0.0
+        steps = int(rng.integers(1, 130))
+        of = int(rng.integers(1, 45))
+        deep = int(rng.integers(6, 8))
+        opts = dict(tune=0, layout=int(rng.integers(0, 2)), variant=int(rng.integers(0, 2)), nt=int(rng.integers(0, 2)),
+                    alternate=int(rng.integers(0, 2)), pair_ty=int(rng.choice([8, 12])), xcd=int(rng.integers(0, 2)),
+                    deep=deep, arith=int(rng.integers(0, 2)), fuse=deep - 1)             # ("fuse" is only the label here)
+        strips = int(rng.integers(1, 4)) if ny >= 36 and k % 2 == 0 else 1
+        if strips > 1:
+            opts.update(layout=1, alternate=0, overlap=int(rng.integers(0, 3)), deep_halo=int(rng.integers(0, 2)),
+                        group_threads=int(rng.integers(0, 2)))
+        out.append((k, nx, ny, tau, u, cx, cy, cr, steps, of, opts, strips))
     return out
 
 
