@@ -772,6 +772,10 @@ def test_reinitialise_and_destroy_release_device_memory(lbm):
     nx, ny = 2048, 512
     with lbm.Context(64, 32) as warm:      # the runtime's one-time allocations (code objects, queues: ~170 MB) happen here
         warm.initialise()
+    # ... and the queue's scratch memory (~29 MB, kept by the runtime): the strict register kernel spills 12 VGPRs
+    with lbm.Context(256, 64, options=dict(tune=0, layout=1, variant=1, nt=1, xcd=1, deep=7)) as warm:
+        warm.initialise()
+        warm.step(12, 0)
     free0, _ = lbm.device_memory(0)
     with lbm.Context(nx, ny, inlet_velocity=0.05) as ctx:
         ctx.initialise()
@@ -790,6 +794,39 @@ def test_reinitialise_and_destroy_release_device_memory(lbm):
         assert used < 3 * 2 * 9 * (nx + 32) * (ny + 12) * 8, used   # two buffers (+ scratch, macros), not 2 x (initialisations)
     free3, _ = lbm.device_memory(0)
     assert abs(free3 - free0) <= 8 << 20, (free0, free3)
+
+
+def test_graphs_and_group_threads_are_released(lbm):
+    """Contexts that captured a launch-group graph (re-initialised in between: the graph holds buffer addresses) and groups with
+    their parked host threads come and go without leaving device memory or threads behind (the runtime's own one-time
+    allocations — graph pools, scratch, per-thread state — are taken by two warm-up rounds: measured, they stop growing there)."""
+    def threads():
+        return int(next(l for l in open("/proc/self/status") if l.startswith("Threads:")).split()[1])
+    base = dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7)
+
+    def round_(k):
+        with lbm.Context(512, 160, inlet_velocity=0.05, options=dict(base, loopback=1, overlap=k % 2)) as ctx:
+            ctx.initialise()
+            ctx.step(120, 0)
+            assert ctx.graph_replays() >= 2
+            ctx.initialise()                       # drops the graph with the buffers it was captured on
+            ctx.step(120, 0)
+            ctx.sync()
+            assert ctx.first_unstable_step() == -1
+        t_before = threads()
+        with lbm.Group(256, 120, 3, options=dict(base, deep=1, group_threads=1)) as g:
+            g.initialise()
+            g.step(60, 0)
+            assert threads() >= t_before + 2       # one parked thread per strip beyond the first
+    for k in range(2):
+        round_(k)
+    free0, _ = lbm.device_memory(0)
+    t0 = threads()
+    for k in range(6):
+        round_(k)
+    free1, _ = lbm.device_memory(0)
+    assert abs(free1 - free0) <= 8 << 20, (free0, free1)
+    assert threads() <= t0, (t0, threads())
 
 
 def test_snapshot_refused_after_trailing_pair(lbm):
