@@ -4,7 +4,9 @@
 // LDS-image kernel k_stepd_tile<32,16,5> (round 2's production shape, no longer built into the library).
 //
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -o tools/colbench tools/colbench.hip
-#include "../highperformancecomputing-latticeboltzmannmethod_amd/csrc/lbm_kernel_col.hpp"
+//        (+ -DLBM_COL_PROF -o tools/colbench_prof: in-kernel phase record, `--prof DIR --filter NAME`)
+#include "experimental/lbm_kernel_slide.hpp"
+#include "experimental/lbm_slide_plan.hpp"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -106,6 +108,43 @@ Variant<T> col_variant(bool nt, bool alt = false, int persist = 0) {
         else hipLaunchKernelGGL((k_stepc_col<T, R, NW, D, false, AR>), grid, dim3(NW * 64), 0, L.s, a, L.extra());
     }};
 }
+// the sliding form (lbm_kernel_slide.hpp): the host deals the segments (lbm_slide_plan.hpp); slots = resident blocks to plan for
+static int g_cus = 256;
+#include <map>
+#include <tuple>
+struct PlanOnDevice { SlideSeg* d = nullptr; int n = 0; int* ticket = nullptr; };
+static int g_stagger = 0;
+template <int D> inline PlanOnDevice slide_table(int nx, int ny, int slots, int H) {
+    static std::map<std::tuple<int, int, int, int>, PlanOnDevice> cache;
+    auto key = std::make_tuple(nx, ny, slots, H);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    SlideGeom g{nx, 0, ny, 0, ny, (int)(0.2 * nx), (int)(0.5 * ny), (int)(0.05 * ny), D, H, slots > 0 ? slots : 2 * g_cus};
+    std::vector<SlideSegHost> plan = slide_plan(g);
+    PlanOnDevice pd; pd.n = (int)plan.size();
+    CK(hipMalloc(&pd.d, sizeof(SlideSeg) * std::max<size_t>(1, plan.size())));
+    CK(hipMemcpy(pd.d, plan.data(), sizeof(SlideSeg) * plan.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc(&pd.ticket, 2048 * sizeof(int))); CK(hipMemset(pd.ticket, 0, 2048 * sizeof(int)));
+    int ng = 0, rows_l = 0, rows_g = 0, maxl = 0, maxg = 0;
+    for (auto& s : plan) { if (s.general) { ++ng; rows_g += s.yb - s.ya; maxg = std::max(maxg, s.yb - s.ya); } else { rows_l += s.yb - s.ya; maxl = std::max(maxl, s.yb - s.ya); } }
+    printf("PLAN %dx%d D=%d slots=%d: %d blocks (%d general), lean rows %d (longest piece %d), general rows %d (longest %d)\n", nx, ny, D, g.slots, pd.n, ng, rows_l, maxl, rows_g, maxg);
+    cache[key] = pd;
+    return pd;
+}
+template <typename T, int R, int NW, int D, int AR>
+Variant<T> slide_variant(bool nt, int slots = 0, int stagger = -1) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "slide R=%d NW=%d D=%d %s s%d g%d", R, NW, D, nt ? "nt" : "  ", slots, stagger);
+    return {nm, D, [=](Lattice<T>& L) {
+        static_assert(sizeof(SlideSeg) == sizeof(SlideSegHost), "one layout");
+        const PlanOnDevice pd = slide_table<D>(L.nx, L.ny, slots, R * NW);
+        SlideArgs sa; sa.segs = pd.d; sa.nblocks = pd.n; sa.cu_ticket = pd.ticket; sa.stagger = stagger >= 0 ? stagger : g_stagger;
+        dim3 grid((sa.nblocks + 7) / 8 * 8);
+        KArgs<T> a = L.args(L.t);
+        if (nt) hipLaunchKernelGGL((k_steps_col<T, R, NW, D, true, AR>), grid, dim3(NW * 64), 0, L.s, a, L.extra(), sa);
+        else hipLaunchKernelGGL((k_steps_col<T, R, NW, D, false, AR>), grid, dim3(NW * 64), 0, L.s, a, L.extra(), sa);
+    }};
+}
 template <typename T, int TX, int TY, int D, int AR>
 Variant<T> tile_variant() {
     char nm[96];
@@ -125,6 +164,13 @@ std::vector<Variant<T>> variants() {
     v.push_back(col_variant<T, 4, 8, 6, AR>(true));
     v.push_back(col_variant<T, 4, 8, 6, AR>(false));
     v.push_back(col_variant<T, 4, 8, 6, AR>(false, true));
+    v.push_back(slide_variant<T, 4, 8, 6, AR>(false));
+    v.push_back(slide_variant<T, 4, 8, 6, AR>(true));
+    v.push_back(slide_variant<T, 4, 8, 5, AR>(false));
+    v.push_back(slide_variant<T, 4, 8, 6, AR>(false, 0, 1));
+    v.push_back(slide_variant<T, 4, 8, 6, AR>(false, 0, 2));
+    v.push_back(slide_variant<T, 4, 8, 6, AR>(false, 0, 3));
+    v.push_back(slide_variant<T, 4, 8, 6, AR>(false, 0, 5));
     return v;
 }
 
@@ -203,10 +249,52 @@ void timeit(int nx, int ny, int reps, int rounds, const std::string& filter) {
     fflush(stdout);
 }
 
+#ifdef LBM_COL_PROF
+// one profiled launch of every variant whose name contains `filter`: the raw marks as CSV (tools/prof_phases.py reads them)
+template <typename T, int AR>
+void profile(int nx, int ny, const std::string& filter, const std::string& outdir) {
+    Lattice<T> L(nx, ny);
+    for (auto& v : variants<T, AR>()) {
+        if (v.name.find(filter) == std::string::npos) continue;
+        const size_t nblk = 8192, nw = 8, n = nblk * nw * PROF_SLOTS;
+        unsigned long long* d; CK(hipMalloc(&d, n * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(lbmk::lbm_prof_buf), &d, sizeof(d)));
+        L.init();
+        for (int i = 0; i < 12; ++i) { v.launch(L); L.flip(v.depth); }
+        CK(hipStreamSynchronize(L.s));
+        CK(hipMemset(d, 0, n * 8));
+        CK(hipEventRecord(L.e0, L.s));
+        v.launch(L); L.flip(v.depth);
+        CK(hipEventRecord(L.e1, L.s));
+        CK(hipEventSynchronize(L.e1));
+        float ms; CK(hipEventElapsedTime(&ms, L.e0, L.e1));
+        std::vector<unsigned long long> h(n);
+        CK(hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost));
+        std::string nm = v.name; for (auto& c : nm) if (c == ' ' || c == '=') c = '_';
+        const std::string path = outdir + "/prof_" + nm + ".csv";
+        FILE* fp = fopen(path.c_str(), "w");
+        fprintf(fp, "# %s %dx%d launch_us=%.2f\nblock,wave,xcc,hwid,realtime", v.name.c_str(), nx, ny, ms * 1e3);
+        for (int k = 0; k < PROF_SLOTS - 2; ++k) fprintf(fp, ",t%d", k);
+        fprintf(fp, "\n");
+        for (size_t b = 0; b < nblk; ++b)
+            for (size_t w = 0; w < nw; ++w) {
+                const unsigned long long* r = &h[(b * nw + w) * PROF_SLOTS];
+                if (!r[PROF_SLOTS - 2]) continue;
+                fprintf(fp, "%zu,%zu,%llu,%llu,%llu", b, w, r[PROF_SLOTS - 1] >> 32, r[PROF_SLOTS - 1] & 0xffffffffull, r[PROF_SLOTS - 2]);
+                for (int k = 0; k < PROF_SLOTS - 2; ++k) fprintf(fp, ",%llu", r[k]);
+                fprintf(fp, "\n");
+            }
+        fclose(fp);
+        printf("PROF %s: %.2f us/launch (with marks) -> %s\n", v.name.c_str(), ms * 1e3, path.c_str());
+        CK(hipFree(d));
+    }
+}
+#endif
+
 int main(int argc, char** argv) {
     int nx = 4096, ny = 1024, reps = 100, rounds = 3;
     bool do_check = true, do_time = true, strict = false;
-    std::string prec = "f64", filter;
+    std::string prec = "f64", filter, profdir;
     int mnx = 0, mny = 0, mlaunch = 1;
     for (int i = 1; i < argc; ++i) {
         std::string k = argv[i];
@@ -219,8 +307,14 @@ int main(int argc, char** argv) {
         else if (k == "--no-time") do_time = false;
         else if (k == "--strict") strict = true;
         else if (k == "--filter") filter = argv[++i];
+        else if (k == "--prof") profdir = argv[++i];
+        else if (k == "--stagger") g_stagger = atoi(argv[++i]);
         else if (k == "--map") { g_map = true; mnx = atoi(argv[++i]); mny = atoi(argv[++i]); mlaunch = atoi(argv[++i]); }
     }
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, 0) == hipSuccess && pr.multiProcessorCount > 0) g_cus = pr.multiProcessorCount; }
+#ifdef LBM_COL_PROF
+    if (!profdir.empty()) { profile<double, AR_CONTRACTED>(nx, ny, filter, profdir); return 0; }
+#endif
     int failures = 0;
     if (g_map) { if (prec == "f64") check<double, AR_CONTRACTED>(mnx, mny, mlaunch); else check<float, AR_CONTRACTED>(mnx, mny, mlaunch); return 0; }
     if (do_check) {
