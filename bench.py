@@ -91,11 +91,14 @@ def cpu_baseline(nx, ny, u_in, budget_s=12.0):
                 except Exception:
                     pass
             (ranks, threads) = max(probe, key=probe.get)
-            steps = max(5, min(400, int(budget_s * probe[(ranks, threads)] * 1e6 / (nx * ny))))
-            best = _time_reference(ref, d, nx, ny, u_in, steps, ranks, threads)
-            return {"value": round(best, 2), "unit": "MLUPS", "cores": ranks * threads, "kind": "reference",
+            # best of three runs of the chosen split (a weak baseline flatters: round 3's single 400-step run read 598 MLUPS where
+            # the same split's own 8-step probe had read 732), each a third of the budget
+            steps = max(5, min(200, int(budget_s / 3 * probe[(ranks, threads)] * 1e6 / (nx * ny))))
+            runs = [_time_reference(ref, d, nx, ny, u_in, steps, ranks, threads) for _ in range(3)]
+            return {"value": round(max(runs), 2), "unit": "MLUPS", "cores": ranks * threads, "kind": "reference",
                     "sample": f"unmodified reference (oracle/_ref/ref_driver, -O3 -ffast-math -mavx2 -mfma -fopenmp), "
-                              f"{nx}x{ny} fp64, {steps} steps incl. its per-step stability scan, {ranks} MPI rank(s) x "
+                              f"{nx}x{ny} fp64, best of three runs of {steps} steps incl. its per-step stability scan "
+                              f"({', '.join(f'{v:.0f}' for v in runs)} MLUPS), {ranks} MPI rank(s) x "
                               f"{threads} OpenMP threads (fastest of the probed splits: "
                               + ", ".join(f"{r}x{t}={v:.0f}" for (r, t), v in sorted(probe.items())) + " MLUPS)"}
         except Exception as e:  # the reference binary does not run on this host: time the port instead
@@ -112,20 +115,113 @@ def cpu_baseline(nx, ny, u_in, budget_s=12.0):
                       f"{steps} steps, {threads} OpenMP threads"}
 
 
-def measured_traffic(nx, local_ny, precision, kernel, layout=""):
-    """The committed counter passes of the dominant kernel on this grid (profiles/traffic.json: FETCH_SIZE, WRITE_SIZE and SQ
-    counters cannot be collected inside a timed run). Returns (entry | None, note)."""
+def _same(a, b):
+    return a.replace(" ", "") == b.replace(" ", "")
+
+
+def kernel_family(kernel):
+    """('k_stepc_col', 'double', depth) etc.: what a sibling entry (other store policy / arithmetic flag) must share."""
+    m = re.match(r"(k_step\w*)<(\w+)", kernel.replace(" ", ""))
+    return (m.group(1), m.group(2), plan_depth_of(kernel)) if m else (kernel, "", 0)
+
+
+def measured_traffic(nx, local_ny, precision, kernel, layout="", build_id=None):
+    """Fallback when the live counter passes cannot run: the committed passes of the dominant kernel on this grid
+    (profiles/traffic.json; every entry carries the build id it was taken on). Exact kernel first; else the nearest sibling
+    (same family, element type and depth, other store policy) flagged `approximate`. Returns (entry | None, note)."""
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         tj = json.load(open(tfile))
     except Exception as e:
         return None, f"profiles/traffic.json unreadable ({e})"
     key = f"{nx}x{local_ny}_{precision}"
-    ents = [e for e in (tj.get(key) or []) if e.get("kernel", "").replace(" ", "") == kernel.replace(" ", "")]
+    allents = tj.get(key) or []
+    ents = [dict(e) for e in allents if _same(e.get("kernel", ""), kernel)]
+    approx = False
+    if not ents:
+        fam = kernel_family(kernel)
+        arith = kernel.replace(" ", "").rstrip(">").split(",")[-1]
+        sib = [dict(e) for e in allents if kernel_family(e.get("kernel", "")) == fam]
+        sib.sort(key=lambda e: e.get("kernel", "").replace(" ", "").rstrip(">").split(",")[-1] != arith)   # same arithmetic first
+        ents, approx = sib, True
     ents.sort(key=lambda e: e.get("layout", "") != layout)      # the pass taken in the same layout first
-    if ents:
-        return ents[0], ents[0].get("source", "profiles/traffic.json")
-    return None, f"no counter pass committed for {key} with {kernel} (profiles/traffic.json)"
+    if not ents:
+        return None, f"no counter pass committed for {key} with {kernel} or a sibling (profiles/traffic.json)"
+    e = ents[0]
+    e["approximate"] = approx
+    e["stale"] = bool(build_id) and e.get("build_id") != build_id
+    note = e.get("source", "profiles/traffic.json") + (f" [sibling {e['kernel']}]" if approx else "")
+    return e, note
+
+
+PMC_GROUPS = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"))
+_INIT_KERNEL = re.compile(r"k_step_site<\w+,1,|k_step_vec<\w+,\d+,1,")      # the collide-only launch of lbm_initialise
+
+
+def live_counters(nx, ny, precision, arith, plan_options, steps, re_number=200.0, timeout=240, keep_dir=None):
+    """The counter passes of THIS binary on THIS plan, taken now: tools/pmc_probe.py (same grid, plan pinned through
+    lbm_plan_options, the bench's own lbm_step(steps) calls) is run as a child under `rocprofv3 --pmc`, one pass per counter
+    group (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950). Returns (entry, note) or (None, why)."""
+    import glob
+    import csv
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    probe_steps = steps if steps <= 240 else 120
+    reps, warm = (6, 1) if nx * ny <= (1 << 24) else (2, 1)
+    base = keep_dir or tempfile.mkdtemp(prefix="lbm_pmc_")
+    tot, disp, kernels, probe = {}, {}, {}, None
+    env = dict(os.environ, TMPDIR="/tmp")
+    for gi, group in enumerate(PMC_GROUPS):
+        d = os.path.join(base, f"pass{gi}_{group[0].lower()}")
+        cmd = [rocprof, "--pmc", *group, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
+               os.path.join(ROOT, "tools", "pmc_probe.py"), "--nx", str(nx), "--ny", str(ny), "--re", repr(re_number), "--precision", precision,
+               "--arith", str(arith), "--plan", plan_options, "--steps", str(probe_steps), "--reps", str(reps), "--warm", str(warm)]
+        try:
+            out = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                 start_new_session=True)
+        except subprocess.TimeoutExpired:
+            return None, f"counter pass {group[0]} timed out after {timeout} s"
+        m = re.search(r'^\{"probe".*$', out.stdout, re.M)
+        if out.returncode != 0 or not m:
+            return None, f"counter pass {group[0]} failed (rc {out.returncode}): {(out.stderr or out.stdout)[-200:]}"
+        probe = json.loads(m.group(0))
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            return None, f"counter pass {group[0]} wrote no counter_collection.csv"
+        for f in files:
+            with open(f, newline="") as fh:
+                for r in csv.DictReader(fh):
+                    k = re.sub(r"\(.*$", "", re.sub(r"^void ", "", r["Kernel_Name"])).replace("lbmk::", "").replace(" ", "")
+                    if not k.startswith("k_step") or _INIT_KERNEL.match(k):
+                        continue
+                    c = r["Counter_Name"]
+                    tot[c] = tot.get(c, 0.0) + float(r["Counter_Value"])
+                    disp[c] = disp.get(c, 0) + 1
+                    kernels.setdefault(c, {}).setdefault(k, 0)
+                    kernels[c][k] += 1
+    if not keep_dir:
+        shutil.rmtree(base, ignore_errors=True)
+    if "FETCH_SIZE" not in tot or "WRITE_SIZE" not in tot or not probe:
+        return None, "counter passes returned no FETCH_SIZE / WRITE_SIZE rows for the step kernels"
+    launches = probe["launches"]
+    if disp["FETCH_SIZE"] != launches or disp["WRITE_SIZE"] != launches:
+        return None, f"dispatch count mismatch: probe issued {launches} step launches, passes saw {disp['FETCH_SIZE']} / {disp['WRITE_SIZE']}"
+    fetch = tot["FETCH_SIZE"] * 1024 * 2 / launches      # KiB -> B; x2: gfx950 tallies the 128-B requests of a coalesced read stream at 64 B
+    write = tot["WRITE_SIZE"] * 1024 / launches
+    e = {"kernel": probe["kernel"], "hbm_bytes_per_launch": int(fetch + write), "fetch_bytes_corrected": int(fetch), "write_bytes": int(write),
+         "launches_sampled": launches, "iterations_per_launch": probe["iterations"] / launches, "build_id": probe["build_id"],
+         "kernels_sampled": kernels["FETCH_SIZE"], "stale": False, "approximate": False, "probe_steps_per_call": probe_steps,
+         "method": "live: tools/pmc_probe.py (plan pinned by lbm_plan_options) as a child under rocprofv3 --pmc, one pass per counter group; "
+                   "KiB -> B; FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section)"}
+    for c, name in (("SQ_INSTS_VALU", "valu_insts_per_launch"), ("SQ_INSTS_LDS", "lds_insts_per_launch"), ("SQ_ACTIVE_INST_VALU", "active_inst_valu"),
+                    ("SQ_BUSY_CYCLES", "busy_cycles"), ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_WAIT_ANY", "wait_any")):
+        if c in tot:
+            e[name] = tot[c] / launches
+    return e, "live counter passes of this binary and plan (rocprofv3 --pmc around tools/pmc_probe.py, taken after the timed region)"
 
 
 def plan_depth_of(kernel):
@@ -133,48 +229,59 @@ def plan_depth_of(kernel):
     return int(next(g for g in m.groups() if g)) if m else 1
 
 
-def roofline_of(lbm, ctx, nx, local_ny, precision, kernel_ms, launches, iterations, steps):
+def roofline_of(lbm, ctx, nx, local_ny, precision, kernel_ms, launches, iterations, steps, arith=1, live=True, re_number=200.0):
     """The `roofline` object for the dominant kernel of a timed call (see the module docstring)."""
     bpl = BYTES_PER_LUP[precision]
     ipl = iterations / max(launches, 1)
     launch_bytes = int(nx * local_ny * bpl * ipl)          # SURVEY §8(d): 144 B (72 B) x the lattice updates of one launch
     kernel = ctx.kernel_name()
-    ent, tnote = measured_traffic(nx, local_ny, precision, kernel, ctx.plan().split("/")[0])
-    plan_depth = plan_depth_of(kernel)
-    scale = ipl / plan_depth          # a short call mixes launch depths (20 = 5+5+5+5 on a six-iteration plan): the counter
-    if abs(scale - 1.0) > 0.01:       # passes belong to the plan's kernel at its own depth
-        tnote += f"; scaled by {ipl:.3f}/{plan_depth} (mixed launch depths in a {steps}-step call)"
+    build_id = lbm.build_id()
+    ent = None
+    tnote = "live counter passes not requested"
+    if live:
+        ent, tnote = live_counters(nx, local_ny, precision, arith, " ".join(f"{k}={v}" for k, v in ctx.plan_options().items()), steps, re_number)
+    if ent is None:
+        live_note = tnote
+        ent, tnote = measured_traffic(nx, local_ny, precision, kernel, ctx.plan().split("/")[0], build_id)
+        tnote += f" (live passes: {live_note})"
     secs = kernel_ms * 1e-3
     achieved = launch_bytes / secs / 1e9 if secs > 0 else 0.0
     r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel, "kernel_ms": round(kernel_ms, 5),
          "algorithmic_bytes_per_launch": launch_bytes, "iterations_per_launch": round(ipl, 4),
          "frac_144B": round(achieved / HBM_PEAK_GBS, 4), "frac_hbm_measured": None, "frac_valu": None,
-         "frac_hbm_fused_minimum": round((launch_bytes / ipl) / secs / 1e9 / HBM_PEAK_GBS, 4) if secs > 0 else None}
+         "frac_hbm_fused_minimum": round((launch_bytes / ipl) / secs / 1e9 / HBM_PEAK_GBS, 4) if secs > 0 else None,
+         "traffic_source": tnote}
     if ent:
-        traffic = int(ent["hbm_bytes_per_launch"] * scale)
+        # bytes per launch as the passes counted them, at the launch depth(s) they were taken at: a fused launch moves about one
+        # read and one write of the lattice whatever its depth, so nothing is rescaled by depth (ADVICE r03); the live passes
+        # replay the timed call's own launch mix
+        traffic = int(ent["hbm_bytes_per_launch"])
+        ipl_t = float(ent.get("iterations_per_launch") or ipl)
         gbs = traffic / secs / 1e9
-        r.update(traffic=traffic, hbm_gbs_measured=round(gbs, 1), frac_hbm_measured=round(gbs / HBM_PEAK_GBS, 4),
-                 hbm_bytes_per_update=round(traffic / (nx * local_ny * ipl), 2),
-                 mlups_per_gbs=round(nx * local_ny * ipl / secs / 1e6 / gbs, 2), traffic_source=tnote)
+        r.update(traffic=traffic, traffic_iterations_per_launch=round(ipl_t, 4), hbm_gbs_measured=round(gbs, 1),
+                 frac_hbm_measured=round(gbs / HBM_PEAK_GBS, 4),
+                 hbm_bytes_per_update=round(traffic / (nx * local_ny * ipl_t), 2),
+                 mlups_per_gbs=round(1000.0 / (traffic / (nx * local_ny * ipl_t)), 2),
+                 traffic_build_id=ent.get("build_id"), stale=bool(ent.get("stale")), approximate=bool(ent.get("approximate")),
+                 fetch_bytes_corrected=ent.get("fetch_bytes_corrected"), write_bytes=ent.get("write_bytes"))
         if ent.get("valu_insts_per_launch"):
-            lane = ent["valu_insts_per_launch"] * 64.0 / (nx * local_ny * plan_depth)      # lane-instructions per lattice update
-            ceil = VALU_LANE_RATE[precision] / lane / 1e6                                     # MLUPS if vector issue were the only limit
+            lane = ent["valu_insts_per_launch"] * 64.0 / (nx * local_ny * ipl_t)      # lane-instructions per lattice update
+            ceil = VALU_LANE_RATE[precision] / lane / 1e6                              # MLUPS if vector issue were the only limit
             r.update(valu_lane_instr_per_update=round(lane, 1), valu_ceiling_mlups=round(ceil, 0),
                      frac_valu=round(nx * local_ny * ipl / secs / 1e6 / ceil, 4),
-                     lds_insts_per_update=round(ent.get("lds_insts_per_launch", 0) * 64.0 / (nx * local_ny * plan_depth), 2))
+                     lds_insts_per_update=round(ent.get("lds_insts_per_launch", 0) * 64.0 / (nx * local_ny * ipl_t), 2))
         if r["frac_valu"] and r["frac_valu"] > r["frac_hbm_measured"]:
             r["bound"] = "valu"      # (the contract's vocabulary has no word for it: vector issue, no MFMA on this path)
-    else:
-        r["traffic_source"] = tnote
     r["note"] = ("achieved/frac = frac_144B: SURVEY 8(d)'s algorithmic bytes (144 B fp64 / 72 B fp32 per lattice update) x the updates of "
                  "one launch / the kernel's live launch time / 8 TB/s — ABOVE 1 because a launch fuses iterations_per_launch "
                  "iterations in registers and so moves ~1/d of the unfused bytes; it is the figure to hold against an unfused "
                  "kernel's roofline (north_star's 70 % = 0.70). frac_hbm_measured = bytes the kernel really moved (PMC FETCH_SIZE x2 + "
-                 "WRITE_SIZE, separate passes, profiles/) / time / 8 TB/s (the streaming ceiling measured on this part is 6.0-6.3 TB/s "
-                 "= 0.75-0.79); frac_valu = vector lane-instructions per update from the SQ pass against 1024 SIMDs x 16 (fp64) or "
-                 "32 (fp32) lanes/clk x 2.4 GHz; bound = the larger of the two; frac_hbm_fused_minimum = one read + one write of the "
-                 "lattice per launch, the least any d-iteration launch can move")
+                 "WRITE_SIZE, separate passes taken by this run on this binary and plan: traffic_source) / time / 8 TB/s (the streaming ceiling "
+                 "measured on this part is 6.0-6.3 TB/s = 0.75-0.79); frac_valu = vector lane-instructions per update from the SQ pass against "
+                 "1024 SIMDs x 16 (fp64) or 32 (fp32) lanes/clk x 2.4 GHz (the chip holds ~1.9 GHz under this load: profiles/r04); "
+                 "bound = the larger of the two; frac_hbm_fused_minimum = one read + one write of the lattice per launch, the least any "
+                 "d-iteration launch can move")
     return r
 
 
@@ -197,6 +304,8 @@ def main():
     ap.add_argument("--no-other-arith", action="store_true", help="skip the run in the other arithmetic mode (profiler passes)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the second, longer window (profiler passes)")
     ap.add_argument("--no-f32-variant", action="store_true", help="skip the single-precision variant (BASELINE.json configs[4]) beside the headline")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not take the counter passes (rocprofv3 child runs after the timed region): "
+                                                               "roofline.traffic then comes from profiles/traffic.json")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -222,6 +331,7 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
     ndev = lbm.device_count()
     device = local_rank % ndev          # (a launcher may expose one device per rank)
+    exit_code = 0
 
     nx = args.nx
     ny_total = args.ny * (world if args.scaling == "weak" else 1)
@@ -257,6 +367,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     ctx.step(args.steps, 0)
+    t_issue = time.perf_counter() - t0      # what the host needed to ISSUE the window (launches, events, exchanges): the floor of a host-bound strip
     fence()
     dt = time.perf_counter() - t0
     ms_total, launches, iterations = ctx.last_step_stats()
@@ -272,15 +383,18 @@ def main():
         dt_sus = time.perf_counter() - t1
     compute_only_ms = None
     if world > 1:
-        tt = torch.tensor([dt, kernel_ms, dt_sus or 0.0], dtype=torch.float64)
+        tt = torch.tensor([dt, kernel_ms, dt_sus or 0.0, t_issue], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, kernel_ms, dt_sus = float(tt[0]), float(tt[1]), (float(tt[2]) if dt_sus else None)
+        dt, kernel_ms, dt_sus, t_issue = float(tt[0]), float(tt[1]), (float(tt[2]) if dt_sus else None), float(tt[3])
+    graph_replays = ctx.graph_replays()
     bad = ctx.first_unstable_step()
     if bad != -1:
         sys.exit(f"simulation unstable at timestep {bad}: result invalid")
     # what ran in the timed region (the parity pass below initialises the context again)
     kernel, plan_used, schedule_used = ctx.kernel_name(), ctx.plan(), ctx.strip_schedule()
-    roof = roofline_of(lbm, ctx, nx, local_ny, args.precision, kernel_ms, launches, iterations, args.steps) if rank == 0 else None
+    arith_id = 1 if args.arith == "contracted" else 0
+    roof = roofline_of(lbm, ctx, nx, local_ny, args.precision, kernel_ms, launches, iterations, args.steps, arith_id,
+                       live=(world == 1 and not args.no_live_pmc), re_number=args.re) if rank == 0 else None
     parity = None
     if world > 1:
         # what the halo traffic costs: the same launches with the exchange skipped (diagnostic pass, results discarded)
@@ -347,10 +461,26 @@ def main():
                                  "ms_per_step": round(dt_sus / sus_steps * 1e3, 5),
                                  "note": "a second, longer window of the same context, same fences; `value` above is the contract's K-step window"}
         if world > 1:
+            graph_opt = next((int(kv.split("=")[1]) for kv in args.set if kv.startswith("graph=")), 1)
             line["strips"] = {"nranks": world, "schedule": schedule_used,
                               "ms_per_step_compute_only": round(compute_only_ms, 5),
-                              "ms_per_step_exchange_exposed": round(dt / args.steps * 1e3 - compute_only_ms, 5)}
+                              "ms_per_step_exchange_exposed": round(dt / args.steps * 1e3 - compute_only_ms, 5),
+                              # slowest rank: host time to issue one iteration's share of launches / events / exchanges in the timed window
+                              "host_issue_us_per_iteration": round(t_issue / args.steps * 1e6, 3),
+                              "gpu_us_per_iteration": round(dt / args.steps * 1e6, 3),
+                              # hipGraph replay of the launch groups: between real peers only on request (--set graph=2; never run
+                              # between two GPUs so far: DESIGN §5 says what to expect with and without it)
+                              "graph": ("replayed" if graph_replays > 0 else ("off (multi-rank default; --set graph=2 asks for it)" if graph_opt < 2 else
+                                        "refused: launch groups issued call by call")),
+                              "graph_replays_rank0": graph_replays,
+                              "halo_bytes_per_face_and_exchange": hr * 9 * ((nx + 2 + 32 + 15) // 16 * 16) * (8 if args.precision == "f64" else 4)}
             line["strips"].update(parity)
+            verdict = str(parity.get("parity", ""))
+            if verdict.startswith("MISMATCH"):
+                line["value_unverified"] = line["value"]
+                line["value"] = None            # as for an unstable run: a wrong halo exchange has no throughput
+            elif verdict != "bit-equal":
+                line["parity_unverified"] = True
         if other is not None:
             line["other_arithmetic"] = other
         if spv is not None:
@@ -360,10 +490,20 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(nx, ny_total, u_in)
         print(json.dumps(line), flush=True)
+        if world > 1:
+            verdict = str((parity or {}).get("parity", ""))
+            if verdict.startswith("MISMATCH"):
+                sys.stderr.write(f"[bench] strips do not reproduce the one-GPU run ({verdict}): the line above is INVALID\n")
+                exit_code = 3
     ctx.close()
     if world > 1:
+        code = torch.tensor([exit_code], dtype=torch.int32)
+        dist.all_reduce(code, op=dist.ReduceOp.MAX)          # every rank leaves with rank 0's verdict
+        exit_code = int(code[0])
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 def single_precision_variant(lbm, device, args):
@@ -386,10 +526,12 @@ def single_precision_variant(lbm, device, args):
             if c.first_unstable_step() != -1:
                 return {"error": "unstable"}
             ms_total, launches, iterations = c.last_step_stats()
-            roof = roofline_of(lbm, c, nx, ny, "f32", ms_total / max(launches, 1), launches, iterations, steps)
+            roof = roofline_of(lbm, c, nx, ny, "f32", ms_total / max(launches, 1), launches, iterations, steps, 1 if args.arith == "contracted" else 0,
+                               live=not args.no_live_pmc)
             out = {"workload": f"D2Q9-BGK cylinder Re=200, {nx}x{ny} f32 (BASELINE.json configs[4]) on ONE GPU", "value": round(nx * ny * steps / dt / 1e6, 1),
                    "unit": "MLUPS", "steps": steps, "kernel": c.kernel_name(), "plan": c.plan()}
-            for k in ("frac_144B", "frac_hbm_measured", "frac_valu", "hbm_gbs_measured", "hbm_bytes_per_update", "mlups_per_gbs", "bound"):
+            for k in ("frac_144B", "frac_hbm_measured", "frac_valu", "hbm_gbs_measured", "hbm_bytes_per_update", "mlups_per_gbs", "bound", "traffic",
+                      "traffic_source", "traffic_build_id", "stale", "approximate", "kernel_ms", "iterations_per_launch"):
                 out[k] = roof.get(k)
             return out
     except Exception as e:      # (a GPU that cannot hold 2 x 2.4 GB beside the headline context: report, do not fail the bench)
@@ -425,7 +567,9 @@ def strip_parity(lbm, ctx, dist, rank, world, nx, ny_total, local_ny, u_in, args
     arithmetic mode (tests/), so the first N>1 line proves exchange_rccl's nranks>1 branch (csrc/lbm_hip.hip; replaces the
     reference's Grid::exchange_ghost_cells, LBMGrid.h:249-283) by itself."""
     import numpy as np
-    its = 24
+    # long enough that a graph-replaying schedule (option graph=2: four launch groups per replay, captured after a first eager
+    # stretch) is compared too: 2 x 4 groups x 6 iterations + 4 x 6 + 1, rounded up; odd, so the call ends on a single iteration
+    its = 97
     try:      # (whatever goes wrong on a rank, it still takes part in the gather below: nobody is left waiting)
         ctx.set_option("trailing_pair", 0)      # the call ends on a single iteration: f_next can be read back
         ctx.initialise()                         # collective (the strip schedule is re-measured): every rank is here

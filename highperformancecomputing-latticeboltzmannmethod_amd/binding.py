@@ -74,6 +74,7 @@ def lib():
         L.lbm_graph_replays.restype = C.c_long; L.lbm_graph_replays.argtypes = [vp]
         L.lbm_kernel_name.argtypes = [vp]; L.lbm_kernel_name.restype = C.c_char_p
         L.lbm_plan.argtypes = [vp]; L.lbm_plan.restype = C.c_char_p
+        L.lbm_plan_options.argtypes = [vp]; L.lbm_plan_options.restype = C.c_char_p
         L.lbm_build_id.restype = C.c_char_p
         L.lbm_runtime_versions.argtypes = [C.POINTER(C.c_int)] * 3
         L.lbm_strip_schedule.argtypes = [vp]; L.lbm_strip_schedule.restype = C.c_char_p
@@ -271,6 +272,10 @@ class Context:
 
     def plan(self):
         return self.L.lbm_plan(self.h).decode()
+
+    def plan_options(self):
+        """The plan as {option: value} (lbm_plan_options): with tune=0 it pins the same plan on another context."""
+        return {k: int(v) for k, v in (kv.split("=") for kv in self.L.lbm_plan_options(self.h).decode().split())}
 
 
 class Group:

@@ -2,6 +2,7 @@
 // lbm_kernels.hpp. Plain HIP runtime + RCCL; no torch types, no CPU fallback.
 #include "lbm_kernels.hpp"
 #include "lbm_col_api.hpp"
+#include "lbm_plan.hpp"
 #include "../../include/lbm_hip.h"
 
 #include <rccl/rccl.h>
@@ -166,7 +167,8 @@ struct lbm_ctx {
     bool last_was_pair = false;   // the last launch fused several iterations: buf[cur^1] is older than steps_done-1
     bool restored = false;   // state came from lbm_load_state: no previous-iteration buffer until the next step
     int tune = 1;        // lbm_initialise times the candidate plans on this device and keeps the fastest
-    char plan_desc[160] = "";
+    char plan_desc[512] = "";
+    char plan_opts[128] = "";    // the plan as lbm_set_option pairs ("layout=1 nt=0 ..."): with tune=0 they reproduce it in another process
     double depth_rel[4] = {2.8, 1.6, 1.12, 1.08};   // cost per iteration of a 1- / 2- / 3- / 4-iteration launch relative to the plan's deep
                                                     // launch (plan_launch's tail split); measured by choose_plan on a single domain,
                                                     // these defaults — 4096x1024 fp64, round 2 — elsewhere (strips: every rank must split alike)
@@ -175,7 +177,7 @@ struct lbm_ctx {
     int overlap = 1;
     bool overlap_pinned = false, deep_pinned = false;   // set through lbm_set_option: the strip tuner leaves them alone
     int skip_exchange = 0;   // DIAGNOSTIC: issue every launch but no halo traffic (times the compute side of a strip run; results invalid)
-    char sched_desc[256] = "";
+    char sched_desc[640] = "";
     int timed_launches = 0, timed_steps = 0;
     long launches_total = 0;
     // communicator
@@ -293,22 +295,11 @@ void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
 // a plan of either uses both depths, and on a context without strip faces seven iterations too, for what a segment leaves
 // over (20 = 7 + 7 + 6; at 4096x1024 fp64 seven iterations run at 160.6 GLUPS against 161.7 for six — eight, 154.3, are
 // not built). Ids 4 / 5 were round 2's 32x16 LDS tiles: retired.
-inline bool deep_is_col(int id) { return id == 6 || id == 7; }
-inline bool deep_valid(int id) { return id == 0 || (id >= 1 && id <= 3) || deep_is_col(id); }
-inline int deep_depth(int id) {
-    static const int d[8] = {0, 6, 7, 8, 0, 0, 5, 6};
-    return id >= 0 && id <= 7 ? d[id] : 0;
-}
 // rows of one band of tiles of a launch of `depth` iterations (the edge bands of a strip are one band each)
 inline int deep_rows(int id, int depth) {
     if (deep_is_col(id)) return col_tile_h(depth);
     return id == 3 ? 32 : 16;
 }
-inline const char* deep_tile(int id) {
-    static const char* t[4] = {"", "64,16", "64,16", "32,32"};
-    return id >= 0 && id <= 3 ? t[id] : "";
-}
-
 // A fused kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt): iterations a.t .. a.t + depth - 1 (depth 2..8).
 template <typename T>
 void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s) {
@@ -812,7 +803,6 @@ inline int alloc_buffers(lbm_ctx* c) {
 // 4096x1024 fp64 depending on the allocation). All candidates compute bit-identical results, so lbm_initialise
 // times each one on the real buffers (12 warm-up iterations, then the faster of two 36-iteration windows) and keeps the fastest together
 // with the very allocation it was measured on.
-struct Plan { int layout, variant, nt, alternate, fuse, ty, xcd; const char* name; int deep = 0; };
 
 inline void apply_plan(lbm_ctx* c, const Plan& pl) {
     configure_layout(c, pl.layout);
@@ -858,83 +848,22 @@ int choose_plan(lbm_ctx* c) {
     const bool strips = (c->comm && c->nranks > 1) || c->group_n > 1 || c->loopback;
     const Plan fixed = {(strips || c->loopback) ? 1 : c->layout, c->variant, c->use_nt, c->alternate, c->fuse, c->pair_ty, c->xcd,
                         "fixed by options", c->deep};
-    std::vector<Plan> cand;
-    const bool vec_ok = (c->nx % vec_width<T>() == 0), p2 = pair_possible(c);
-    // "small": 1024-cell tiles make at most two rounds of one block per CU (fp32: two blocks per CU)
-    const bool small_grid = (size_t)c->nx * c->nyl <= (size_t)2048 * c->num_cus * (c->esize == 4 ? 2 : 1);
+    const bool p2 = pair_possible(c);
+    (void)p2;
+    const bool vec_ok = (c->nx % vec_width<T>() == 0);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     configure_layout(c, 1);
     const size_t need = 2 * buffer_bytes(c);
     // tiny grids are launch/latency bound (nothing to choose); huge ones cannot afford a second live allocation
     const bool can_tune = c->tune && (size_t)c->nx * c->nyl >= (1u << 16) && 2 * need + (1u << 28) < free_b;
-    // the strip rule (see below): a function of the global grid and the number of strips only, so that every rank —
+    // the strip rule (lbm_plan.hpp): a function of the global grid and the number of strips only, so that every rank —
     // measuring or not — issues the same launch depths
     const int nstrips = c->group_n > 1 ? c->group_n : (c->comm && c->nranks > 1) ? c->nranks : 1;
-    // 0: three iterations on 64x12 LDS tiles in pairs between exchanges; 1: six iterations on 64x16 LDS tiles of 1024 threads
-    // (one cell per thread: the shortest launch, and on strips this short the chain edge band -> exchange -> edge band IS
-    // the time step); 7: six iterations on 64x32 regions held in registers (four cells per thread: the highest throughput).
-    // One GPU, one rank of N exchanging with itself through RCCL, 4096 columns (tools/strip_proxy.py, profiles/r03): 128 rows
-    // 7.6 us per iteration on the LDS tiles against 8.5 in registers; 256 rows 13.2 against 11.6.
-    const int strip_rows = c->p.ny / nstrips;
-    const int strip_deep = !strips ? 0 : strip_rows >= 192 ? 7 : strip_rows >= 64 ? 1 : 0;
-    const char* const deep_name[2] = {"row-interleaved/6-step 64x16", "row-interleaved/6-step 64x32 in registers"};
-    static thread_local char dn[3][96];
-    if (strip_deep) {
-        snprintf(dn[0], sizeof(dn[0]), "%s (default, not measured)", deep_name[strip_deep == 7]);
-        snprintf(dn[1], sizeof(dn[1]), "%s/nt-store/xcd", deep_name[strip_deep == 7]);
-        snprintf(dn[2], sizeof(dn[2]), "%s/xcd", deep_name[strip_deep == 7]);
-    }
-    if (!c->tune) cand.push_back(fixed);
-    else if (!can_tune) {
-        if (strip_deep) cand.push_back({1, 1, 1, 0, 6, 12, 1, dn[0], strip_deep});
-        else if (strips) cand.push_back({1, 1, 1, 0, p2 ? 3 : 1, 12, 1, "row-interleaved (default, not measured)"});
-        else cand.push_back({0, vec_ok ? 0 : 1, 1, 0, p2 ? 3 : 1, 12, 0, "planar (default, not measured)"});
-    } else {
-        // Strips exchange GR rows x 9 sub-rows as one contiguous run: row-interleaved only. Every rank must issue the
-        // same sequence of launches (one exchange per launch), so the fusion depth and tile shape of a strip run are
-        // fixed by rule — a function of the global grid and the number of strips only (above); only rank-local choices
-        // (the store policy) are measured.
-        if (strip_deep) {
-            cand.push_back({1, 1, 1, 0, 6, 12, 1, dn[1], strip_deep});
-            cand.push_back({1, 1, 0, 0, 6, 12, 1, dn[2], strip_deep});
-        } else if (strips) {
-            const int f = p2 ? 3 : 1;
-            cand.push_back({1, 1, 1, 0, f, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
-            cand.push_back({1, 1, 1, 0, f, 12, 0, "row-interleaved/3-step 64x12/nt-store"});
-            cand.push_back({1, 1, 0, 1, f, 12, 1, "row-interleaved/3-step 64x12/alternate/xcd"});
-        } else {
-            if (p2) cand.push_back({1, 1, 1, 0, 4, 8, 1, "row-interleaved/4-step 64x8/nt-store/xcd"});
-            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-store/xcd", 7});   // k_stepc_col
-            cand.push_back({1, 1, 1, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/nt-store/xcd", 6});
-            // (non-temporal stores pay where most of the lattice fits the 256 MiB Infinity Cache — 4096x1024 fp64: +1 % — and
-            // cost 3-12 % on the large grids: 8192x2048 fp64 168 -> 173 GLUPS, 16384x4096 fp32 259 -> 290 without them)
-            cand.push_back({1, 1, 0, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/xcd", 7});
-            cand.push_back({1, 1, 0, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/xcd", 6});
-            cand.push_back({1, 1, 0, 1, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/alternate/xcd", 7});
-            cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x16/nt-store/xcd", 1});
-            if (small_grid && !face_south(c) && !face_north(c)) {   // one round of LDS-filling tiles: a launch's load and store phases are paid once per 7-8 iterations
-                cand.push_back({1, 1, 1, 0, 7, 12, 1, "row-interleaved/7-step 64x16/nt-store/xcd", 2});
-                cand.push_back({1, 1, 1, 0, 8, 12, 1, "row-interleaved/8-step 32x32/nt-store/xcd", 3});
-            }
-            if (p2) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
-            if (p2) cand.push_back({1, 1, 1, 0, 3, 8, 1, "row-interleaved/3-step 64x8/nt-store/xcd"});
-            if (p2) cand.push_back({1, 1, 1, 0, 2, 12, 1, "row-interleaved/2-step 64x12/nt-store/xcd"});
-            if (p2) cand.push_back({1, 1, 1, 0, 2, 8, 1, "row-interleaved/2-step 64x8/nt-store/xcd"});
-            cand.push_back({1, 1, 1, 0, 1, 0, 0, "row-interleaved/site/nt-store"});
-            cand.push_back({1, 1, 0, 1, 1, 0, 0, "row-interleaved/site/alternate"});
-        }
-        if (!strips) {
-            if (p2) cand.push_back({0, 0, 1, 0, 4, 8, 1, "planar/4-step 64x8/nt-store/xcd"});
-            cand.push_back({0, 0, 1, 0, 6, 12, 1, "planar/6-step 64x32 in registers/nt-store/xcd", 7});
-            if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 1, "planar/3-step 64x12/nt-store/xcd"});
-            if (p2) cand.push_back({0, 0, 1, 0, 3, 12, 0, "planar/3-step 64x12/nt-store"});
-            if (p2) cand.push_back({0, 0, 1, 0, 2, 12, 0, "planar/2-step 64x12/nt-store"});
-            if (p2) cand.push_back({0, 0, 0, 1, 3, 12, 0, "planar/3-step 64x12/alternate"});
-            if (vec_ok) cand.push_back({0, 0, 0, 1, 1, 0, 0, "planar/vec16B/alternate"});
-            cand.push_back({0, 1, 0, 1, 1, 0, 0, "planar/site/alternate"});
-        }
-    }
+    PlanQuery q;
+    q.nx = c->nx; q.nyl = c->nyl; q.ny_glob = c->p.ny; q.esize = (int)c->esize; q.num_cus = c->num_cus; q.nstrips = nstrips; q.strips = strips;
+    q.vec_ok = vec_ok; q.tune = c->tune != 0; q.can_tune = can_tune; q.faces = face_south(c) || face_north(c);
+    const std::vector<Plan> cand = plan_candidates(q, fixed);
     free_buffers(c);                                // a second lbm_initialise starts from no population buffers
     // First round: every candidate once; the three fastest keep their allocations. Final round: those three again with
     // longer windows (candidates within 2 % of each other are common and the first round cannot tell them apart).
@@ -958,20 +887,30 @@ int choose_plan(lbm_ctx* c) {
         std::stable_sort(top.begin(), top.end(), [](const Kept& x, const Kept& y) { return x.ms < y.ms; });
         while (top.size() > keep) { for (void* q : top.back().buf) if (q) (void)hipFree(q); top.pop_back(); }
     }
+    std::string finalists;
     if (top.size() > 1) {
         for (Kept& t : top) {
             apply_plan(c, cand[(size_t)t.k]);
             c->buf[0] = t.buf[0]; c->buf[1] = t.buf[1];
             // (longer windows: the finalists are often 2-3 % apart — store policy, walk direction — and the alternating walk
-            // only shows what it gains from the Infinity Cache once a few launches have gone both ways)
-            float a = 0.f, b = 0.f;
-            int rc = time_plan<T>(c, &a, 120);
-            if (!rc) rc = time_plan<T>(c, &b, 120);
+            // only shows what it gains from the Infinity Cache once a few launches have gone both ways. Round 3 took the faster
+            // of two 120-iteration windows and picked three different plans in three sessions at 16384x4096 fp32: now the MEDIAN
+            // of three windows of at least 50 ms each — time_plan returns the faster of two halves, so six in all.)
+            const int window = std::max(120, (int)std::ceil(25.0 / std::max(1e-4, (double)t.ms)));
+            float w[3] = {0.f, 0.f, 0.f};
+            int rc = LBM_OK;
+            for (int r = 0; r < 3 && !rc; ++r) rc = time_plan<T>(c, &w[r], window);
             c->buf[0] = c->buf[1] = nullptr;
             if (rc) { drop_all(); return rc; }
-            t.ms = std::min(a, b);
+            std::sort(w, w + 3);
+            t.ms = w[1];
         }
         std::stable_sort(top.begin(), top.end(), [](const Kept& x, const Kept& y) { return x.ms < y.ms; });
+        for (const Kept& t : top) {
+            char fb[160];
+            snprintf(fb, sizeof(fb), "%s%s %.2f", finalists.empty() ? "" : "; ", cand[(size_t)t.k].name.c_str(), t.ms * 1e3f);
+            finalists += fb;
+        }
         while (top.size() > 1) { for (void* q : top.back().buf) if (q) (void)hipFree(q); top.pop_back(); }
     }
     const int best = top[0].k;
@@ -981,9 +920,13 @@ int choose_plan(lbm_ctx* c) {
     c->buf[0] = best_buf[0]; c->buf[1] = best_buf[1];
     c->launches_total = 0;
     c->last_was_pair = false;
-    if (cand.size() > 1) snprintf(c->plan_desc, sizeof(c->plan_desc), "%s (fastest of %zu measured, %.1f us/iteration)",
-                                  cand[best].name, cand.size(), best_ms * 1e3f);
-    else snprintf(c->plan_desc, sizeof(c->plan_desc), "%s", cand[best].name);
+    if (cand.size() > 1 && !finalists.empty())
+        snprintf(c->plan_desc, sizeof(c->plan_desc), "%s (fastest of %zu measured, %.1f us/iteration; finalists, median of three windows, us/iteration: %s)",
+                 cand[best].name.c_str(), cand.size(), best_ms * 1e3f, finalists.c_str());
+    else if (cand.size() > 1) snprintf(c->plan_desc, sizeof(c->plan_desc), "%s (fastest of %zu measured, %.1f us/iteration)",
+                                       cand[best].name.c_str(), cand.size(), best_ms * 1e3f);
+    else snprintf(c->plan_desc, sizeof(c->plan_desc), "%s", cand[best].name.c_str());
+    snprintf(c->plan_opts, sizeof(c->plan_opts), "%s", plan_option_string(c->layout, c->variant, c->use_nt, c->alternate, c->pair_ty, c->xcd, c->fuse, c->deep).c_str());
     if (cand.size() > 1 && c->deep && !strips && best_ms > 0.f) {
         // What the shallow launches cost on THIS grid and allocation, for plan_launch's split of a segment's last iterations
         // (a single domain only: the strips of a run must all split alike, so they keep the fixed table).
@@ -1008,6 +951,21 @@ int choose_plan(lbm_ctx* c) {
 
 template <typename T> int do_steps(lbm_ctx** cs, int n, int nsteps, int of);
 int allreduce_doubles(lbm_ctx* c, double* vals, int n, int op);
+
+// What the ranks must agree on before the collective trials of tune_strip_schedule: packed so that ONE MIN-reduction yields the
+// minimum and (negated) the maximum of every pin. v = {go, pin_overlap or -1, -(pin_overlap or -1), pin_deep or -1, -(...)}.
+inline void strip_pins_pack(bool go, bool overlap_pinned, int overlap, bool deep_pinned, int deep_halo, double v[5]) {
+    const double po = overlap_pinned ? (double)overlap : -1.0, pd = deep_pinned ? (double)deep_halo : -1.0;
+    v[0] = go ? 1.0 : 0.0; v[1] = po; v[2] = -po; v[3] = pd; v[4] = -pd;
+}
+// after the MIN-reduction: false = the ranks disagree (some pinned, some not, or to different values)
+inline bool strip_pins_agree(const double v[5], int* go, int* overlap_pinned, int* overlap, int* deep_pinned, int* deep_halo) {
+    if (v[1] != -v[2] || v[3] != -v[4]) return false;
+    *go = v[0] > 0.5;
+    *overlap_pinned = v[1] >= 0.0; if (*overlap_pinned) *overlap = (int)v[1];
+    *deep_pinned = v[3] >= 0.0; if (*deep_pinned) *deep_halo = (int)v[3];
+    return true;
+}
 
 // Strip schedule by measurement (one rank of a multi-process run; collective: every rank runs the same trials and sees
 // the same reduced timings, so all ranks choose alike). The schedules — exchange overlapped with the interior rows of the
@@ -1036,13 +994,23 @@ int tune_strip_schedule(lbm_ctx* c) {
     };
     describe(multi ? "fixed by options" : "default", 0, 0.0);
     if (!multi) return LBM_OK;
-    {   // The trials below are COLLECTIVE (send/recv with the neighbours, an all-reduce per schedule): whether they run must be
-        // the same decision on every rank. Strips may differ in height (191 rows over 8 ranks: seven of 24 and one of 23) and,
-        // in principle, in their options, so the decision is reduced over the ranks first: all of them tune, or none does.
-        double go = (c->tune && !(c->overlap_pinned && c->deep_pinned) && c->nyl >= 4 * GR) ? 1.0 : 0.0;
-        int rc = allreduce_doubles(c, &go, 1, 2);      // MIN
+    {   // The trials below are COLLECTIVE (send/recv with the neighbours, an all-reduce per schedule): whether they run — and WHICH
+        // of them run: a pinned half of the schedule removes trials — must be the same decision on every rank. Strips may differ
+        // in height (191 rows over 8 ranks: seven of 24 and one of 23) and, in principle, in their options, so the decision and
+        // the pins are reduced over the ranks first (one MIN over {go, pin, -pin, ...}): all of them tune the same list, or the
+        // call fails on every rank alike (ranks with different pins ran different numbers of collective trials and
+        // the first multi-process lbm_initialise hung in RCCL instead of returning an error).
+        double v[5];
+        strip_pins_pack(c->tune && c->nyl >= 4 * GR, c->overlap_pinned, c->overlap, c->deep_pinned, c->deep_halo, v);
+        int rc = allreduce_doubles(c, v, 5, 2);      // MIN
         if (rc) return rc;
-        if (go < 0.5) return LBM_OK;
+        int go = 0, po = 0, pd = 0, ov = c->overlap, dh = c->deep_halo;
+        if (!strip_pins_agree(v, &go, &po, &ov, &pd, &dh))
+            return fail(LBM_ERR_ARG, "the ranks of this run pin different strip schedules (lbm_set_option overlap / deep_halo): set the same on every rank");
+        c->overlap_pinned = po != 0; c->deep_pinned = pd != 0;
+        if (po) c->overlap = ov;
+        if (pd) c->deep_halo = dh;
+        if (!go || (po && pd)) return LBM_OK;
     }
     const int keep_tp = c->trailing_pair;
     c->trailing_pair = 1;
@@ -1077,6 +1045,12 @@ int tune_strip_schedule(lbm_ctx* c) {
         res.push_back(r);
     }
     const int tried = (int)res.size();
+    std::string trials;      // every schedule's first-round time (MAX over the ranks), for the log: the margin of the choice
+    for (const Res& r : res) {
+        char tb[48];
+        snprintf(tb, sizeof(tb), "%so%dd%d %.2f", trials.empty() ? "" : ", ", r.o, r.d, r.ms * 1e3 / TIMED);
+        trials += tb;
+    }
     std::stable_sort(res.begin(), res.end(), [](const Res& x, const Res& y) { return x.ms < y.ms; });
     if (res.size() > 2) res.resize(2);
     if (res.size() == 2) {
@@ -1093,6 +1067,9 @@ int tune_strip_schedule(lbm_ctx* c) {
     if (!res.empty()) {
         c->overlap = res[0].o; c->deep_halo = res[0].d;
         describe("fastest", tried, res[0].ms * 1e3 / TIMED);
+        const size_t n = strlen(c->sched_desc);
+        if (n + 1 < sizeof(c->sched_desc))
+            snprintf(c->sched_desc + n, sizeof(c->sched_desc) - n, "; first round, us/iteration by (overlap, deep_halo): %s", trials.c_str());
     }
     // back to iteration 0 with fresh halos
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -2094,20 +2071,48 @@ long lbm_graph_replays(const lbm_ctx* c) { return c ? c->graph_replays : 0; }
 const char* lbm_kernel_name(const lbm_ctx* c) {
     if (!c) return "";
     static thread_local char name[96];
-    const char* t = c->p.precision == LBM_PRECISION_F32 ? "float" : "double";
-    const char* nt = c->use_nt ? "true" : "false";
-    const int ar = c->arith;
-    if (c->fuse > 2 && deep_is_col(c->deep)) snprintf(name, sizeof(name), "k_stepc_col<%s,%d,%d,%d,%s,%d>", t, COL_R, COL_NW, deep_depth(c->deep), nt, ar);
-    else if (c->fuse > 2 && c->deep) snprintf(name, sizeof(name), "k_stepd_tile<%s,%s,%d,%d>", t, deep_tile(c->deep), deep_depth(c->deep), ar);
-    else if (c->fuse == 4) snprintf(name, sizeof(name), "k_step4_tile<%s,8,%d,%d>", t, c->esize == 8 ? 1024 : 512, ar);
-    else if (c->fuse > 1) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%d>", c->fuse, t, c->pair_ty,
-                                   c->pair_ty == 12 ? (c->fuse == 3 ? 1024 : 768) : 512, ar);
-    else if (use_vec(c)) snprintf(name, sizeof(name), "k_step_vec<%s,%d,0,%s,%d>", t, (int)(16 / c->esize), nt, ar);
-    else snprintf(name, sizeof(name), "k_step_site<%s,0,%s,%d>", t, nt, ar);
+    snprintf(name, sizeof(name), "%s", plan_kernel_name(c->fuse, c->deep, c->pair_ty, c->use_nt, c->arith, (int)c->esize, use_vec(c)).c_str());
     return name;
 }
 
+/* TEST HOOK (no device needed): the candidates lbm_initialise would time for a whole-domain context of this grid, one per line:
+ * "name|lbm_set_option pairs|dominant kernel|iterations per launch". */
+int lbm_debug_plan_candidates(int nx, int ny, int precision, int arith, int num_cus, char* out, int cap) {
+    if (!out || cap < 1 || nx < 1 || ny < 1) return fail(LBM_ERR_ARG, "bad argument");
+    PlanQuery q;
+    q.nx = nx; q.nyl = ny; q.ny_glob = ny; q.esize = precision == LBM_PRECISION_F32 ? 4 : 8; q.num_cus = num_cus > 0 ? num_cus : 256;
+    q.vec_ok = nx % (16 / q.esize) == 0;
+    const Plan none{};
+    std::string text;
+    for (const Plan& pl : plan_candidates(q, none)) {
+        const int fuse = pl.fuse > 0 ? pl.fuse : 1;
+        text += pl.name + "|" + plan_option_string(pl.layout, pl.variant, pl.nt, pl.alternate, pl.ty, pl.xcd, fuse, pl.deep) + "|" +
+                plan_kernel_name(fuse, pl.deep, pl.ty ? pl.ty : 8, pl.nt, arith, q.esize, pl.variant == 0 && q.vec_ok) + "|" + std::to_string(pl.deep ? deep_depth(pl.deep) : fuse) + "\n";
+    }
+    if ((int)text.size() + 1 > cap) return fail(LBM_ERR_ARG, "buffer too small (%zu bytes needed)", text.size() + 1);
+    memcpy(out, text.c_str(), text.size() + 1);
+    return LBM_OK;
+}
+
+/* TEST HOOK (no device needed): the decision tune_strip_schedule takes from per-rank pins. ranks x {tune-able, overlap_pinned,
+ * overlap, deep_pinned, deep_halo}; returns LBM_OK and the agreed {go, overlap_pinned, overlap, deep_pinned, deep_halo} or LBM_ERR_ARG. */
+int lbm_debug_strip_pins(const int* per_rank5, int nranks, int* agreed5) {
+    if (!per_rank5 || !agreed5 || nranks < 1) return fail(LBM_ERR_ARG, "null argument");
+    double m[5] = {1e30, 1e30, 1e30, 1e30, 1e30};
+    for (int r = 0; r < nranks; ++r) {
+        double v[5];
+        const int* q = per_rank5 + 5 * r;
+        strip_pins_pack(q[0] != 0, q[1] != 0, q[2], q[3] != 0, q[4], v);
+        for (int k = 0; k < 5; ++k) m[k] = std::min(m[k], v[k]);        // what allreduce_doubles(..., MIN) returns on every rank
+    }
+    agreed5[2] = agreed5[4] = -1;
+    if (!strip_pins_agree(m, &agreed5[0], &agreed5[1], &agreed5[2], &agreed5[3], &agreed5[4]))
+        return fail(LBM_ERR_ARG, "the ranks pin different strip schedules");
+    return LBM_OK;
+}
+
 const char* lbm_plan(const lbm_ctx* c) { return c ? c->plan_desc : ""; }
+const char* lbm_plan_options(const lbm_ctx* c) { return c ? c->plan_opts : ""; }
 
 #ifndef LBM_BUILD_ID_STR
 #define LBM_BUILD_ID_STR "unversioned-----"

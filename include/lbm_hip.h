@@ -197,8 +197,21 @@ int  lbm_last_step_stats(lbm_ctx* c, double* ms_total, int* launches, int* itera
  * 0 also where the capture was refused and the eager path runs). No reference counterpart: the reference has no GPU path. */
 long lbm_graph_replays(const lbm_ctx* c);
 const char* lbm_kernel_name(const lbm_ctx* c);
-/* The plan lbm_initialise settled on (layout / kernel / store policy / traversal), for logs. */
+/* The plan lbm_initialise settled on (layout / kernel / store policy / traversal), for logs; where it was measured, with the
+ * finalists' times (median of three windows each) so that the margin of the choice is visible. */
 const char* lbm_plan(const lbm_ctx* c);
+/* The same plan as lbm_set_option pairs, "layout=1 variant=1 nt=0 alternate=1 pair_ty=12 xcd=1 deep=7": set
+ * on a fresh context together with "tune" 0 they reproduce the plan in another process (bench.py's counter passes run
+ * the benchmarked plan in a child process under rocprofv3). No reference counterpart. */
+const char* lbm_plan_options(const lbm_ctx* c);
+/* Test hook, callable without a device: what the ranks of a strip run agree on before the collective schedule trials of
+ * lbm_initialise (csrc/lbm_hip.hip tune_strip_schedule). per_rank5 = nranks x {may tune, overlap pinned, overlap, deep_halo pinned,
+ * deep_halo}; agreed5 = {tune, overlap pinned, overlap, deep_halo pinned, deep_halo}. LBM_ERR_ARG when the ranks pin different
+ * schedules (they would otherwise run different numbers of collective trials). Replaces nothing in the reference. */
+int lbm_debug_strip_pins(const int* per_rank5, int nranks, int* agreed5);
+/* Test hook, callable without a device: the candidate plans lbm_initialise would time on a whole-domain context of this grid
+ * (csrc/lbm_plan.hpp), one per line: "name|lbm_set_option pairs|dominant kernel|iterations per launch". */
+int lbm_debug_plan_candidates(int nx, int ny, int precision, int arith, int num_cus, char* out, int cap);
 /* SHA-256 (16 hex digits) of the sources this binary was compiled from (csrc/ and this header); build.py rebuilds
  * when it differs from the tree, bench.py prints it. */
 const char* lbm_build_id(void);

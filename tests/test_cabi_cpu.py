@@ -80,3 +80,31 @@ def test_argument_errors_are_reported_without_a_device(pkg):
     assert L.lbm_steps_done(None) == -1
     assert L.lbm_set_option(None, b"tune", 0) == -1
     L.lbm_destroy(None)                                                     # destroying nothing is a no-op
+
+
+def test_strip_schedule_pins_are_agreed_over_the_ranks(pkg):
+    """the schedule trials of lbm_initialise are collective, so ranks with different overlap / deep_halo pins must get
+    an error on every rank, not a different number of trials (a hang in RCCL). lbm_debug_strip_pins runs the very decision
+    functions of tune_strip_schedule (strip_pins_pack -> MIN over the ranks -> strip_pins_agree) without a device."""
+    lib = ctypes.CDLL(pkg.lib_path())
+    lib.lbm_debug_strip_pins.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+
+    def agree(ranks):
+        flat = (ctypes.c_int * (5 * len(ranks)))(*[v for r in ranks for v in r])
+        out = (ctypes.c_int * 5)()
+        rc = lib.lbm_debug_strip_pins(flat, len(ranks), out)
+        return rc, list(out)
+
+    # nobody pins anything: tune, nothing pinned
+    assert agree([(1, 0, 1, 0, 1)] * 4) == (0, [1, 0, -1, 0, -1])
+    # everybody pins overlap=2: agreed, the deep-halo half is still measured
+    assert agree([(1, 1, 2, 0, 1)] * 3) == (0, [1, 1, 2, 0, -1])
+    # one strip too short to tune: nobody tunes
+    rc, out = agree([(1, 0, 1, 0, 1), (0, 0, 1, 0, 1)])
+    assert rc == 0 and out[0] == 0
+    # one rank pins overlap, the other does not / pins another value: error on every rank
+    assert agree([(1, 1, 1, 0, 1), (1, 0, 1, 0, 1)])[0] < 0
+    assert agree([(1, 1, 1, 0, 1), (1, 1, 0, 0, 1)])[0] < 0
+    assert agree([(1, 0, 1, 1, 0), (1, 0, 1, 1, 1)])[0] < 0
+    # both halves pinned alike everywhere
+    assert agree([(1, 1, 0, 1, 1)] * 8) == (0, [1, 1, 0, 1, 1])
