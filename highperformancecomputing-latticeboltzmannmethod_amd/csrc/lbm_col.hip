@@ -7,15 +7,17 @@ namespace lbmk {
 
 template <typename T>
 void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool contracted, hipStream_t s) {
-#define LBM_KC(D_) do { \
-        constexpr int OW_ = col_tile_w(D_), OH_ = col_tile_h(D_); \
+#define LBM_KC(D_, R_, NT_, AR_) do { \
+        constexpr int OW_ = col_tile_w(D_), OH_ = col_tile_h(D_, R_); \
         const int nb_ = ((a.nx + OW_ - 1) / OW_) * ((a.y_cnt + OH_ - 1) / OH_ + (a.y_cnt2 + OH_ - 1) / OH_); \
         const dim3 gridc((unsigned)((nb_ + 7) / 8 * 8)), blockc(COL_NW * 64); \
-        if (nt) { if (contracted) hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, true, AR_CONTRACTED>), gridc, blockc, 0, s, a, e); \
-                  else hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, true, AR_STRICT>), gridc, blockc, 0, s, a, e); } \
-        else { if (contracted) hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, false, AR_CONTRACTED>), gridc, blockc, 0, s, a, e); \
-               else hipLaunchKernelGGL((k_stepc_col<T, COL_R, COL_NW, D_, false, AR_STRICT>), gridc, blockc, 0, s, a, e); } } while (0)
-    if (depth == 5) LBM_KC(5); else if (depth == 7) LBM_KC(7); else LBM_KC(6);
+        hipLaunchKernelGGL((k_stepc_col<T, R_, COL_NW, D_, NT_, AR_>), gridc, blockc, 0, s, a, e); } while (0)
+#define LBM_KD(D_) do { \
+        if (contracted) { if (nt) LBM_KC(D_, RC, true, AR_CONTRACTED); else LBM_KC(D_, RC, false, AR_CONTRACTED); } \
+        else { if (nt) LBM_KC(D_, RS, true, AR_STRICT); else LBM_KC(D_, RS, false, AR_STRICT); } } while (0)
+    constexpr int RC = col_rows_per_thread((int)sizeof(T), false), RS = col_rows_per_thread((int)sizeof(T), true);
+    if (depth == 5) LBM_KD(5); else if (depth == 7) LBM_KD(7); else LBM_KD(6);
+#undef LBM_KD
 #undef LBM_KC
 }
 

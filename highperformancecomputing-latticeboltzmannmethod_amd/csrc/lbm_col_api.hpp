@@ -6,12 +6,17 @@
 
 namespace lbmk {
 
-constexpr int COL_R = 4, COL_NW = 8;      // rows per thread x waves per block: a 64 x 32 region, two blocks per CU
+constexpr int COL_NW = 8;                 // waves per block; two blocks per CU
+// rows per thread: 4 (a 64 x 32 region) — except fp64 STRICT arithmetic, whose collision needs a dozen more live registers than
+// 128 VGPRs leave beside 4 x 9 fp64 populations: 3 rows (64 x 24), 122 VGPRs, no scratch. Round 3's strict kernels spilled 12
+// VGPRs (44 B of scratch per lane, 20 % more HBM writes); measured at 4096x1024 (tools/colbench, round 4): 129.9 GLUPS on
+// 3 rows x five iterations against 106-114 on 4 rows. Contracted arithmetic is faster on 4 rows (158-163 against 145-150).
+constexpr int col_rows_per_thread(int esize, bool strict) { return (esize == 8 && strict) ? 3 : 4; }
 // output tile of a launch of `depth` iterations
 constexpr int col_tile_w(int depth) { return 64 - 2 * (depth - 1); }
-constexpr int col_tile_h(int depth) { return COL_R * COL_NW - 2 * (depth - 1); }
+constexpr int col_tile_h(int depth, int rows_per_thread) { return rows_per_thread * COL_NW - 2 * (depth - 1); }
 
-// k_stepc_col<T, COL_R, COL_NW, depth, nt, arith> over the rows a.y_lo.. / a.y_lo2.. of the launch (depth 5, 6 or — whole
+// k_stepc_col<T, rows per thread, COL_NW, depth, nt, arith> over the rows a.y_lo.. / a.y_lo2.. of the launch (depth 5, 6 or — whole
 // domains only: a strip's ghost rows go six deep — 7)
 template <typename T>
 void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool contracted, hipStream_t s);

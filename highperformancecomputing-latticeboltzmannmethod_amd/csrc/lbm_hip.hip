@@ -296,8 +296,8 @@ void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
 // over (20 = 7 + 7 + 6; at 4096x1024 fp64 seven iterations run at 160.6 GLUPS against 161.7 for six — eight, 154.3, are
 // not built). Ids 4 / 5 were round 2's 32x16 LDS tiles: retired.
 // rows of one band of tiles of a launch of `depth` iterations (the edge bands of a strip are one band each)
-inline int deep_rows(int id, int depth) {
-    if (deep_is_col(id)) return col_tile_h(depth);
+inline int deep_rows(const lbm_ctx* c, int id, int depth) {
+    if (deep_is_col(id)) return col_tile_h(depth, col_rows_per_thread((int)c->esize, c->arith == 0));
     return id == 3 ? 32 : 16;
 }
 // A fused kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt): iterations a.t .. a.t + depth - 1 (depth 2..8).
@@ -637,7 +637,7 @@ int issue_before(lbm_ctx* c, const Launch& L) {
         HIPCHK(hipGetLastError());
         return LBM_OK;
     }
-    const int E = c->deep_now ? deep_rows(c->deep, L.depth) : L.depth > 1 ? c->pair_ty : GR;   // one tile band
+    const int E = c->deep_now ? deep_rows(c, c->deep, L.depth) : L.depth > 1 ? c->pair_ty : GR;   // one tile band
     if (L.kind == KIND_EXTENDED) {   // all rows of the strip PLUS the EXT ghost rows next to each internal face
         const int es = face_south(c) ? EXT : 0, en = face_north(c) ? EXT : 0;
         int e0 = face_south(c) ? E : 0, e1 = face_north(c) ? E : 0;

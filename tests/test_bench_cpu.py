@@ -91,18 +91,25 @@ def test_strip_parity_checksums():
 
 
 def test_roofline_object_from_a_committed_pass():
-    """roofline_of on the headline grid with the register kernel: the contract's frac is the 144 B figure (above 1 for a fused
-    launch), the measured HBM and vector-issue fractions come from profiles/traffic.json and stay below 1, bound = the larger."""
+    """roofline_of on the headline grid with the register kernel, live passes off (no GPU here): the contract's frac is the 144 B
+    figure (above 1 for a fused launch), the measured HBM and vector-issue fractions come from profiles/traffic.json — flagged
+    stale when the table was taken on another build — and stay below 1, bound = the larger; nothing is rescaled by depth."""
     b = load_bench()
+
+    class Lbm:
+        @staticmethod
+        def build_id(): return "0123456789abcdef"
 
     class Ctx:
         def kernel_name(self): return "k_stepc_col<double,4,8,6,false,1>"
         def plan(self): return "row-interleaved/6-step 64x32 in registers/xcd (fastest of 27 measured, 26.9 us/iteration)"
-    r = b.roofline_of(None, Ctx(), 4096, 1024, "f64", 0.160, 1000, 6000, 6000)
+        def plan_options(self): return dict(layout=1, variant=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=7)
+    r = b.roofline_of(Lbm, Ctx(), 4096, 1024, "f64", 0.160, 1000, 6000, 6000, live=False)
     assert r["iterations_per_launch"] == 6.0 and r["algorithmic_bytes_per_launch"] == 4096 * 1024 * 144 * 6
     assert abs(r["frac"] - 4096 * 1024 * 144 * 6 / 0.160e-3 / 8e12) < 1e-3 and r["frac"] == r["frac_144B"] > 2.0
     assert r["traffic"] and 0.3 < r["frac_hbm_measured"] < 1.0 and 0.2 < r["frac_valu"] < 1.0
     assert r["bound"] == ("valu" if r["frac_valu"] > r["frac_hbm_measured"] else "hbm")
     assert abs(r["mlups_per_gbs"] - 1000.0 / r["hbm_bytes_per_update"]) < 0.05
-    r5 = b.roofline_of(None, Ctx(), 4096, 1024, "f64", 0.140, 4, 20, 20)      # a 20-step call: mixed depths, traffic scaled
-    assert abs(r5["traffic"] / r["traffic"] - 5.0 / 6.0) < 1e-6 and "scaled" in r5["traffic_source"]
+    assert r["stale"] is True and len(r["traffic_build_id"]) == 16 and r["approximate"] is False and "live passes" in r["traffic_source"]
+    r5 = b.roofline_of(Lbm, Ctx(), 4096, 1024, "f64", 0.140, 4, 20, 20, live=False)      # a 20-step call: the table's bytes as they are
+    assert r5["traffic"] == r["traffic"] and r5["traffic_iterations_per_launch"] == 6.0

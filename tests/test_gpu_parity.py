@@ -887,7 +887,9 @@ def test_fp32_tracks_the_oracle_on_fused_plans_1024x256(lbm):
             out[plan] = ctx.macros()
     er, eu = macro_errors(*out["auto"], *ref)
     print(f"fp32 vs the fp64 oracle, 1024x256 x {steps}: rho {er:.3e}, u {eu:.3e}")
-    assert er < 1e-3 and eu < 1e-3, (er, eu)
+    # stated tolerance 2e-4 = about twice what was measured on MI355X (rho 1.2e-5, u 9.2e-5; SURVEY §8d C5: "≈1e-4 rel on u after
+    # 1000 steps; state the tolerance measured") — round 3 asserted 1e-3, ten times the measurement
+    assert er < 2e-4 and eu < 2e-4, (er, eu)
     for plan, m in out.items():
         for a, b in zip(out["auto"], m):
             assert np.array_equal(a, b), plan
@@ -896,7 +898,7 @@ def test_fp32_tracks_the_oracle_on_fused_plans_1024x256(lbm):
         ctx.step(steps, 0)
         cr, cu = macro_errors(*ctx.macros(), *ref)
         print(f"fp32 contracted vs the fp64 oracle: rho {cr:.3e}, u {cu:.3e}")
-        assert cr < 1e-3 and cu < 1e-3, (cr, cu)
+        assert cr < 2e-4 and cu < 2e-4, (cr, cu)
     record("c2_1024x256_f32_vs_oracle_1000", strict_rho=er, strict_u=eu, contracted_rho=cr, contracted_u=cu)
 
 

@@ -164,6 +164,9 @@ std::vector<Variant<T>> variants() {
     v.push_back(col_variant<T, 4, 8, 6, AR>(true));
     v.push_back(col_variant<T, 4, 8, 6, AR>(false));
     v.push_back(col_variant<T, 4, 8, 6, AR>(false, true));
+    v.push_back(col_variant<T, 3, 8, 5, AR>(true));
+    v.push_back(col_variant<T, 3, 8, 6, AR>(true));
+    v.push_back(col_variant<T, 3, 8, 6, AR>(false, true));
     v.push_back(slide_variant<T, 4, 8, 6, AR>(false));
     v.push_back(slide_variant<T, 4, 8, 6, AR>(true));
     v.push_back(slide_variant<T, 4, 8, 5, AR>(false));
