@@ -151,6 +151,7 @@ struct lbm_ctx {
     int variant = 0;     // single-iteration kernel: 0 = k_step_vec when nx % V == 0, 1 = k_step_site
     int alternate = 1;   // walk the rows bottom-up / top-down on alternate steps (Infinity Cache reuse)
     int use_nt = 0;      // non-temporal stores in the step kernel
+    int use_ntl = 0;     // non-temporal level-1 loads in the register kernel (k_stepc_col)
     int fuse = 1;        // iterations fused per launch where the schedule allows: 1, 2 (k_step2_tile) or 3 (k_step3_tile)
     int pair_ty = 8;     // tile height of the fused kernels (8 or 12)
     int xcd = 0;         // fused kernels: remap blocks so that each XCD walks a contiguous run of tiles
@@ -309,6 +310,7 @@ void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream
     e.small = ((c->total + (size_t)c->pitch) * c->esize + 1024 < (size_t(1) << 32)) ? 1 : 0;   // 32-bit byte offsets (+ one row of slack)
     e.xcd = c->xcd;
     e.nt = c->use_nt;
+    e.ntl = c->use_ntl;
     const bool fast = c->arith == AR_CONTRACTED;
     if (c->deep_now && deep_is_col(shape)) {    // D iterations with the lattice in registers (k_stepc_col, lbm_col.hip)
         launch_col<T>(a, e, depth, c->use_nt != 0, fast, s);
@@ -806,7 +808,7 @@ inline int alloc_buffers(lbm_ctx* c) {
 
 inline void apply_plan(lbm_ctx* c, const Plan& pl) {
     configure_layout(c, pl.layout);
-    c->variant = pl.variant; c->use_nt = pl.nt; c->alternate = pl.alternate; c->fuse = pl.fuse > 0 ? pl.fuse : 1; c->xcd = pl.xcd;
+    c->variant = pl.variant; c->use_nt = pl.nt; c->use_ntl = pl.ntl; c->alternate = pl.alternate; c->fuse = pl.fuse > 0 ? pl.fuse : 1; c->xcd = pl.xcd;
     if (pl.ty) c->pair_ty = pl.ty;
     c->deep = pl.deep;
 }
@@ -847,7 +849,7 @@ template <typename T>
 int choose_plan(lbm_ctx* c) {
     const bool strips = (c->comm && c->nranks > 1) || c->group_n > 1 || c->loopback;
     const Plan fixed = {(strips || c->loopback) ? 1 : c->layout, c->variant, c->use_nt, c->alternate, c->fuse, c->pair_ty, c->xcd,
-                        "fixed by options", c->deep};
+                        "fixed by options", c->deep, c->use_ntl};
     const bool p2 = pair_possible(c);
     (void)p2;
     const bool vec_ok = (c->nx % vec_width<T>() == 0);
@@ -926,7 +928,7 @@ int choose_plan(lbm_ctx* c) {
     else if (cand.size() > 1) snprintf(c->plan_desc, sizeof(c->plan_desc), "%s (fastest of %zu measured, %.1f us/iteration)",
                                        cand[best].name.c_str(), cand.size(), best_ms * 1e3f);
     else snprintf(c->plan_desc, sizeof(c->plan_desc), "%s", cand[best].name.c_str());
-    snprintf(c->plan_opts, sizeof(c->plan_opts), "%s", plan_option_string(c->layout, c->variant, c->use_nt, c->alternate, c->pair_ty, c->xcd, c->fuse, c->deep).c_str());
+    snprintf(c->plan_opts, sizeof(c->plan_opts), "%s", plan_option_string(c->layout, c->variant, c->use_nt, c->alternate, c->pair_ty, c->xcd, c->fuse, c->deep, c->use_ntl).c_str());
     if (cand.size() > 1 && c->deep && !strips && best_ms > 0.f) {
         // What the shallow launches cost on THIS grid and allocation, for plan_launch's split of a segment's last iterations
         // (a single domain only: the strips of a run must all split alike, so they keep the fixed table).
@@ -2010,13 +2012,14 @@ int lbm_load_state(lbm_ctx* c, const char* path) {
 int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     if (!c || !key) return fail(LBM_ERR_ARG, "null argument");
     const std::string k(key);
-    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "tune" || k == "pair" || k == "fuse" || k == "pair_ty" || k == "loopback" || k == "deep" || k == "arith"))
+    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "ntl" || k == "tune" || k == "pair" || k == "fuse" || k == "pair_ty" || k == "loopback" || k == "deep" || k == "arith"))
         return fail(LBM_ERR_ARG, "option %s must be set before lbm_initialise", key);
     if (k == "variant") c->variant = (int)value;
     else if (k == "timing") c->timing = (int)value;
     else if (k == "alternate") c->alternate = (int)value;
     else if (k == "layout") c->layout = (int)value ? 1 : 0;
     else if (k == "nt") c->use_nt = (int)value ? 1 : 0;
+    else if (k == "ntl") c->use_ntl = (int)value ? 1 : 0;
     else if (k == "fuse") { if (value < 1 || value > 4) return fail(LBM_ERR_ARG, "fuse must be 1, 2, 3 or 4 (4: tile kernel, no strip faces)"); c->fuse = (int)value; c->deep = 0; }
     else if (k == "deep") {     // k_stepd_tile: 1: 6 iterations on 64x16 tiles, 2: 7 on 64x16, 3: 8 on 32x32 (1024 threads);
                                 // k_stepc_col (registers): 6 / 7: 5 / 6 iterations on 64x32 regions. 2 and 3: whole-domain launches only.
@@ -2086,7 +2089,7 @@ int lbm_debug_plan_candidates(int nx, int ny, int precision, int arith, int num_
     std::string text;
     for (const Plan& pl : plan_candidates(q, none)) {
         const int fuse = pl.fuse > 0 ? pl.fuse : 1;
-        text += pl.name + "|" + plan_option_string(pl.layout, pl.variant, pl.nt, pl.alternate, pl.ty, pl.xcd, fuse, pl.deep) + "|" +
+        text += pl.name + "|" + plan_option_string(pl.layout, pl.variant, pl.nt, pl.alternate, pl.ty, pl.xcd, fuse, pl.deep, pl.ntl) + "|" +
                 plan_kernel_name(fuse, pl.deep, pl.ty ? pl.ty : 8, pl.nt, arith, q.esize, pl.variant == 0 && q.vec_ok) + "|" + std::to_string(pl.deep ? deep_depth(pl.deep) : fuse) + "\n";
     }
     if ((int)text.size() + 1 > cap) return fail(LBM_ERR_ARG, "buffer too small (%zu bytes needed)", text.size() + 1);

@@ -163,11 +163,14 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
         if (LEAN) {
             const unsigned ub = (unsigned)(Yr + ry0 + GR) * pitchB + (unsigned)(a.xoff + X0) * (unsigned)sizeof(T) + KB;   // wave-uniform
             const unsigned voff = (unsigned)lane * (unsigned)sizeof(T);
+            auto load_all = [&]<int AUX>() {
 #pragma unroll
-            for (int j = 0; j < R; ++j)
+                for (int j = 0; j < R; ++j)
 #pragma unroll
-                for (int i = 0; i < Q; ++i)
-                    g[j][i] = buf_load<T>(rsrc, voff, ub + (unsigned)j * pitchB + (unsigned)i * planeB - (unsigned)cy(i) * pitchB - (unsigned)(cx(i) * (int)sizeof(T)));
+                    for (int i = 0; i < Q; ++i)
+                        g[j][i] = buf_load<T, AUX>(rsrc, voff, ub + (unsigned)j * pitchB + (unsigned)i * planeB - (unsigned)cy(i) * pitchB - (unsigned)(cx(i) * (int)sizeof(T)));
+            };
+            if (e.ntl) load_all.template operator()<2>(); else load_all.template operator()<0>();      // (block-uniform)
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 bad |= any_unstable(g[j]);

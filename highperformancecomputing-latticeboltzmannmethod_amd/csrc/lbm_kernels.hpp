@@ -166,12 +166,12 @@ typedef unsigned lbm_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_desc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000);   // raw, no range limit
 }
-template <typename T> __device__ __forceinline__ T buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
-template <> __device__ __forceinline__ double buf_load<double>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
-}
-template <> __device__ __forceinline__ float buf_load<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+// AUX: cache policy of the load (0 default; 2 = nt, non-temporal: the line is not kept for re-use — round 4: the register kernel's
+// level-1 loads read every line once per launch, and with nt loads + plain stores it runs 2-4 % faster at 4096x1024 fp64, 164-167
+// against 158-163 GLUPS; with nt loads AND nt stores 140: the plan measurement chooses)
+template <typename T, int AUX = 0> __device__ __forceinline__ T buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
+    else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
 }
 template <bool NT> __device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(lbm_u32x2, v), r, voff, soff, NT ? 2 : 0);   // aux 2 = nt
@@ -424,6 +424,7 @@ template <typename T> struct K2Extra {
     int small;   // the buffer is below 4 GiB: the lean path of k_step3_tile may address it with 32-bit byte offsets
     int xcd;     // remap the blocks so that every XCD walks one contiguous run of tiles (run-time: scalar index arithmetic only)
     int nt;      // non-temporal stores (run-time in the fused tile kernels: one block-uniform branch around the nine stores)
+    int ntl;     // non-temporal LOADS at level 1 of the register kernel (run-time: one block-uniform branch around its 36 loads)
 };
 
 // the nine stores of one cell, plain or non-temporal (block-uniform choice)

@@ -14,8 +14,9 @@ namespace lbmk {
 // layout 0 planar / 1 row-interleaved; variant 0 k_step_vec / 1 k_step_site for single iterations; nt: non-temporal stores;
 // alternate: walk direction alternates per launch; fuse: iterations per launch of the tile kernels (1..4) or of the deep shape;
 // ty: tile height of the two- / three-iteration tile kernels (8 or 12); xcd: XCD-aware tile walk; deep: 0, or the deep shape
-// (1..3: k_stepd_tile six / seven / eight iterations; 6 / 7: k_stepc_col five / six iterations in registers)
-struct Plan { int layout, variant, nt, alternate, fuse, ty, xcd; std::string name; int deep = 0; };
+// (1..3: k_stepd_tile six / seven / eight iterations; 6 / 7: k_stepc_col five / six iterations in registers); ntl: the register
+// kernel's level-1 loads are non-temporal
+struct Plan { int layout, variant, nt, alternate, fuse, ty, xcd; std::string name; int deep = 0; int ntl = 0; };
 
 inline bool deep_is_col(int id) { return id == 6 || id == 7; }
 inline bool deep_valid(int id) { return id == 0 || (id >= 1 && id <= 3) || deep_is_col(id); }
@@ -70,6 +71,7 @@ inline std::vector<Plan> plan_candidates(const PlanQuery& q, const Plan& fixed) 
     if (strip_deep) {
         cand.push_back({1, 1, 1, 0, 6, 12, 1, deep_name + "/nt-store/xcd", strip_deep});
         cand.push_back({1, 1, 0, 0, 6, 12, 1, deep_name + "/xcd", strip_deep});
+        if (strip_deep == 7) cand.push_back({1, 1, 0, 0, 6, 12, 1, deep_name + "/nt-load/xcd", strip_deep, 1});
         return cand;
     }
     if (q.strips) {
@@ -86,6 +88,10 @@ inline std::vector<Plan> plan_candidates(const PlanQuery& q, const Plan& fixed) 
     cand.push_back({1, 1, 0, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/xcd", 7});
     cand.push_back({1, 1, 0, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/xcd", 6});
     cand.push_back({1, 1, 0, 1, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/alternate/xcd", 7});
+    // (round 4: non-temporal level-1 LOADS with plain stores: 164-167 against 158-163 GLUPS at 4096x1024 fp64)
+    cand.push_back({1, 1, 0, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-load/xcd", 7, 1});
+    cand.push_back({1, 1, 0, 1, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-load/alternate/xcd", 7, 1});
+    cand.push_back({1, 1, 0, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/nt-load/xcd", 6, 1});
     cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x16/nt-store/xcd", 1});
     if (small_grid && !q.faces) {   // one round of LDS-filling tiles: a launch's load and store phases are paid once per 7-8 iterations
         cand.push_back({1, 1, 1, 0, 7, 12, 1, "row-interleaved/7-step 64x16/nt-store/xcd", 2});
@@ -123,12 +129,13 @@ inline std::string plan_kernel_name(int fuse, int deep, int pair_ty, int nt, int
 }
 
 // the plan as lbm_set_option pairs: `deep` (which sets the depth of its launches itself) or `fuse`, never both
-inline std::string plan_option_string(int layout, int variant, int nt, int alternate, int pair_ty, int xcd, int fuse, int deep) {
+inline std::string plan_option_string(int layout, int variant, int nt, int alternate, int pair_ty, int xcd, int fuse, int deep, int ntl = 0) {
     char b[128];
     snprintf(b, sizeof(b), "layout=%d variant=%d nt=%d alternate=%d pair_ty=%d xcd=%d", layout, variant, nt, alternate, pair_ty ? pair_ty : 8, xcd);
     std::string s(b);
     if (deep) s += " deep=" + std::to_string(deep);
     else s += " fuse=" + std::to_string(fuse > 0 && fuse <= 4 ? fuse : 1);
+    if (ntl) s += " ntl=1";
     return s;
 }
 

@@ -63,6 +63,9 @@ PLANS = {
     "fast-planar-deep8": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=3, arith=1),
     "fast-rowil-col6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
     "fast-planar-col5": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=6, arith=1),
+    # non-temporal level-1 loads in the register kernel (round 4: a store-policy-like choice of the plan measurement)
+    "rowil-col6-ntl-alt": dict(tune=0, layout=1, variant=1, nt=0, ntl=1, alternate=1, pair_ty=12, xcd=1, deep=7),
+    "fast-rowil-col6-ntl": dict(tune=0, layout=1, variant=1, nt=0, ntl=1, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
 }
 FAST = [k for k, v in PLANS.items() if v and v.get("arith")]
 

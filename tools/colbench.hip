@@ -20,6 +20,7 @@ using namespace lbmk;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
 static bool g_map = false;
+static int g_ntl = 0;       // --ntl 1: non-temporal level-1 loads in the register kernel
 template <typename T>
 struct Lattice {
     int nx, ny, pitch, xoff;
@@ -60,7 +61,7 @@ struct Lattice {
         a.tau_inv = (T)(1.0 / 0.6); a.u_in = (T)u_in; a.unstable_t = d_unst; a.t = depth_t; a.t_base = d_zero;
         return a;
     }
-    K2Extra<T> extra() { K2Extra<T> e; e.feq_in = d_feq; e.xcd = 1; e.nt = 1; e.small = (total * sizeof(T) + 4096 < (size_t(1) << 32)) ? 1 : 0; return e; }
+    K2Extra<T> extra() { K2Extra<T> e; e.feq_in = d_feq; e.xcd = 1; e.nt = 1; e.ntl = g_ntl; e.small = (total * sizeof(T) + 4096 < (size_t(1) << 32)) ? 1 : 0; return e; }
     void init() {
         InitArgs<T> ia;
         ia.a = A; ia.b = B; ia.plane = plane; ia.pitch = pitch; ia.xoff = xoff; ia.nx = nx; ia.ny_loc = ny;
@@ -311,6 +312,7 @@ int main(int argc, char** argv) {
         else if (k == "--strict") strict = true;
         else if (k == "--filter") filter = argv[++i];
         else if (k == "--prof") profdir = argv[++i];
+        else if (k == "--ntl") g_ntl = atoi(argv[++i]);
         else if (k == "--stagger") g_stagger = atoi(argv[++i]);
         else if (k == "--map") { g_map = true; mnx = atoi(argv[++i]); mny = atoi(argv[++i]); mlaunch = atoi(argv[++i]); }
     }
