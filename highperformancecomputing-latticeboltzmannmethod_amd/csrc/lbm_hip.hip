@@ -2097,6 +2097,28 @@ int lbm_debug_plan_candidates(int nx, int ny, int precision, int arith, int num_
     return LBM_OK;
 }
 
+/* TEST HOOK (device 0): strict_div2 (the shared-reciprocal form of the collision's two divisions by rho, lbm_kernels.hpp) beside
+ * the compiler's IEEE divisions on the same operands: q1,q2 = strict_div2(a1,a2,b); r1,r2 = a1/b, a2/b. Host arrays of n doubles. */
+int lbm_debug_strict_div2(const double* a1, const double* a2, const double* b, int n, double* q1, double* q2, double* r1, double* r2) {
+    if (!a1 || !a2 || !b || !q1 || !q2 || !r1 || !r2 || n < 1) return fail(LBM_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(0));
+    double* d = nullptr;
+    const size_t nb = (size_t)n * sizeof(double);
+    HIPCHK(hipMalloc(&d, 7 * nb));
+    int rc = LBM_OK;
+    auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == LBM_OK) rc = fail(LBM_ERR_HIP, "%s", hipGetErrorString(e)); };
+    chk(hipMemcpy(d, a1, nb, hipMemcpyHostToDevice)); chk(hipMemcpy(d + n, a2, nb, hipMemcpyHostToDevice)); chk(hipMemcpy(d + 2 * (size_t)n, b, nb, hipMemcpyHostToDevice));
+    if (rc == LBM_OK) {
+        hipLaunchKernelGGL(k_debug_strict_div2<0>, dim3((n + 255) / 256), dim3(256), 0, nullptr, d, d + n, d + 2 * (size_t)n, n, d + 3 * (size_t)n, d + 4 * (size_t)n, d + 5 * (size_t)n, d + 6 * (size_t)n);
+        chk(hipGetLastError());
+        chk(hipDeviceSynchronize());
+        chk(hipMemcpy(q1, d + 3 * (size_t)n, nb, hipMemcpyDeviceToHost)); chk(hipMemcpy(q2, d + 4 * (size_t)n, nb, hipMemcpyDeviceToHost));
+        chk(hipMemcpy(r1, d + 5 * (size_t)n, nb, hipMemcpyDeviceToHost)); chk(hipMemcpy(r2, d + 6 * (size_t)n, nb, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
 /* TEST HOOK (no device needed): the decision tune_strip_schedule takes from per-rank pins. ranks x {tune-able, overlap_pinned,
  * overlap, deep_pinned, deep_halo}; returns LBM_OK and the agreed {go, overlap_pinned, overlap, deep_pinned, deep_halo} or LBM_ERR_ARG. */
 int lbm_debug_strip_pins(const int* per_rank5, int nranks, int* agreed5) {

@@ -188,6 +188,11 @@ template <bool NT> __device__ __forceinline__ void buf_store(float v, __amdgpu_b
 // operations on the same values in the same order => the same bits as the compiler's two expansions and as the oracle's divsd
 // (every strict parity test holds the populations to np.array_equal), for 13 instead of ~26 instructions and a dozen fewer live
 // registers. (A run that blows up is flagged by |f| > 1e5 long before rho or rho*u leave the range where no scaling happens.)
+// RANGE of the bit-identity (tests/test_gpu_thin_spots.py::test_strict_div2_equals_ieee_division_in_its_range holds it on 4 M random
+// operands through lbm_debug_strict_div2): denominators in [2^-20, 2^20], numerators 0 or of magnitude in [2^-400, 2^400] —
+// populations of a stable run live in [1e-3, 1e1]. Outside it the chain is NOT an IEEE division: a -0 numerator gives +0 (the sign
+// of a zero velocity is erased by the equilibrium's bracket and compares equal in every accessor), denormal quotients and
+// exponent gaps beyond the fp64 range are not rescaled, rho == 0 gives NaN where IEEE gives +-inf (both flagged unstable).
 __device__ __forceinline__ void strict_div2(double& a1, double& a2, double b) {
     double r = __builtin_amdgcn_rcp(b);
     double e = __builtin_fma(-b, r, 1.0);
@@ -199,7 +204,17 @@ __device__ __forceinline__ void strict_div2(double& a1, double& a2, double b) {
     q = a2 * r;
     a2 = __builtin_fma(__builtin_fma(-b, q, a2), r, q);
 }
-__device__ __forceinline__ void strict_div2(float& a1, float& a2, float b) { a1 /= b; a2 /= b; }   // (fp32 has no oracle to be bit-equal to: plain divisions)
+__device__ __forceinline__ void strict_div2(float& a1, float& a2, float b) { a1 /= b; a2 /= b; }
+// test kernel (lbm_debug_strict_div2): strict_div2 beside the compiler's own IEEE divisions, element by element
+template <int UNUSED = 0>      // (a template: the header is included by three translation units)
+__global__ void k_debug_strict_div2(const double* a1, const double* a2, const double* b, int n, double* q1, double* q2, double* r1, double* r2) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double x = a1[k], y = a2[k];
+    strict_div2(x, y, b[k]);
+    q1[k] = x; q2[k] = y;
+    r1[k] = a1[k] / b[k]; r2[k] = a2[k] / b[k];
+}   // (fp32 has no oracle to be bit-equal to: plain divisions)
 
 // collision_step for one cell, LBMSolver.h:101-123 (moments i = 0..8 ascending from 0, N7).
 template <typename T, int AR = AR_STRICT>

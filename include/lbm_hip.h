@@ -176,7 +176,7 @@ int  lbm_load_state(lbm_ctx* c, const char* path);
  *                 blocks, two per CU: large grids; a plan of this family uses both depths to split a call without a slow
  *                 tail). Strips use 1, 6, 7 (a ghost frame is six rows deep) with one exchange per launch; 4 / 5 (round 2's
  *                 32x16 LDS tiles) are retired,
- *                 "arith" 0 strict IEEE collision (bit-identical to the CPU oracle) | 1 FMA-contracted (<= 1e-10)
+ *                 "arith" 0 strict IEEE collision (bit-identical to the CPU oracle for normal-range operands: lbm_debug_strict_div2) | 1 FMA-contracted (<= 1e-10)
  *   strips:       "overlap" 0 launch and exchange serialised | 1 edge bands first, the exchange overlapped with the interior
  *                 rows of the SAME launch | 2 the exchange overlapped with the interior rows of the NEXT (extended)
  *                 launch; "deep_halo" 1|0 one exchange per two launches (both measured at lbm_initialise when a
@@ -205,6 +205,10 @@ const char* lbm_plan(const lbm_ctx* c);
  * on a fresh context together with "tune" 0 they reproduce the plan in another process (bench.py's counter passes run
  * the benchmarked plan in a child process under rocprofv3). No reference counterpart. */
 const char* lbm_plan_options(const lbm_ctx* c);
+/* Test hook (device 0): the strict collision's two divisions by rho (LBMSolver.h:108-109) share one reciprocal chain
+ * (csrc/lbm_kernels.hpp strict_div2); this runs it beside the compiler's IEEE divisions: q1,q2 = strict_div2(a1,a2,b), r1,r2 = a1/b,
+ * a2/b, n host doubles each. Bit-identical for denominators in [2^-20, 2^20] and numerators 0 or of magnitude in [2^-400, 2^400]. */
+int lbm_debug_strict_div2(const double* a1, const double* a2, const double* b, int n, double* q1, double* q2, double* r1, double* r2);
 /* Test hook, callable without a device: what the ranks of a strip run agree on before the collective schedule trials of
  * lbm_initialise (csrc/lbm_hip.hip tune_strip_schedule). per_rank5 = nranks x {may tune, overlap pinned, overlap, deep_halo pinned,
  * deep_halo}; agreed5 = {tune, overlap pinned, overlap, deep_halo pinned, deep_halo}. LBM_ERR_ARG when the ranks pin different

@@ -137,3 +137,37 @@ def test_the_drivers_own_calls_at_4096x1024_against_the_oracle(lbm):
             print(f"driver window, arith={arith} [{kernel}, {launches} launches]: rho {er:.2e} u {eu:.2e} max|df| {ef:.2e}")
             assert er < TOL and eu < TOL and ef < TOL, (arith, er, eu, ef)
             record(f"c3_driver_window_5_plus_20_arith{arith}", rho=er, u=eu, max_abs_df=ef, kernel=kernel, launches=launches)
+
+
+def test_strict_div2_equals_ieee_division_in_its_range(lbm):
+    """strict mode is 'IEEE op by op', but its two divisions by rho share one reciprocal chain without v_div_scale /
+    v_div_fixup (csrc/lbm_kernels.hpp strict_div2). Held bit for bit against the compiler's own IEEE division on 4 M random
+    operands of the documented range — denominators in [2^-20, 2^20] (rho ~ 1), numerators 0 or |a| in [2^-400, 2^400] — and
+    the documented deviations outside it are what they are said to be (a -0 numerator gives +0)."""
+    import ctypes
+    L = ctypes.CDLL(lbm.lib_path())
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.lbm_debug_strict_div2.argtypes = [dp, dp, dp, ctypes.c_int, dp, dp, dp, dp]
+    rng = np.random.default_rng(20261004)
+    n = 1 << 22
+
+    def run(a1, a2, b):
+        out = [np.empty(len(b)) for _ in range(4)]
+        args = [np.ascontiguousarray(v, dtype=np.float64) for v in (a1, a2, b)]
+        assert L.lbm_debug_strict_div2(*[v.ctypes.data_as(dp) for v in args], len(b), *[v.ctypes.data_as(dp) for v in out]) == 0
+        return out
+
+    def rand(lo, hi, size):      # magnitudes log-uniform over [2^lo, 2^hi], random sign
+        return np.ldexp(rng.uniform(0.5, 1.0, size), rng.integers(lo + 1, hi + 1, size)) * rng.choice([-1.0, 1.0], size)
+
+    b = np.abs(rand(-20, 20, n))
+    b[: n // 2] = rng.uniform(1e-3, 1e1, n // 2)          # where the densities of a run live
+    a1, a2 = rand(-400, 400, n), rand(-400, 400, n)
+    a1[::7] = rng.uniform(-1.0, 1.0, len(a1[::7]))        # momenta of a run
+    a2[::5] = 0.0
+    q1, q2, r1, r2 = run(a1, a2, b)
+    assert np.array_equal(q1.view(np.uint64), r1.view(np.uint64)) and np.array_equal(q2.view(np.uint64), r2.view(np.uint64))
+    # outside the range: documented, not hidden
+    q1, q2, r1, r2 = run(np.array([-0.0, 1.0]), np.array([0.0, 1.0]), np.array([1.5, 0.0]))
+    assert q1[0] == 0.0 and not np.signbit(q1[0]) and np.signbit(r1[0])      # -0 / b: +0 here, -0 in IEEE
+    assert np.isnan(q1[1]) and np.isinf(r1[1])                               # a / 0: NaN here, inf in IEEE (both flagged unstable)
