@@ -459,7 +459,11 @@ def main():
         if dt_sus:
             line["sustained"] = {"value": round(cells * sus_steps / dt_sus / 1e6, 1), "unit": "MLUPS", "steps": sus_steps,
                                  "ms_per_step": round(dt_sus / sus_steps * 1e3, 5),
-                                 "note": "a second, longer window of the same context, same fences; `value` above is the contract's K-step window"}
+                                 "note": "a second, longer window of the same context, same fences; `value` above is the contract's K-step window. "
+                                         "Why a short window reads lower (profiles/r04/README.md, kernel trace of the driver's call): K = 20 is three "
+                                         "launches, 6+7+7 — the seven-iteration launches a remainder needs run 3-4 % slower per iteration than the plan's "
+                                         "six, the first launch after the fence another ~4 % (idle chip), and ~20 us of fence-to-first-kernel and "
+                                         "completion-to-host latency fall inside a 0.54 ms window; there is no gap between the kernels"}
         if world > 1:
             graph_opt = next((int(kv.split("=")[1]) for kv in args.set if kv.startswith("graph=")), 1)
             line["strips"] = {"nranks": world, "schedule": schedule_used,

@@ -165,6 +165,8 @@ std::vector<Variant<T>> variants() {
     v.push_back(col_variant<T, 4, 8, 6, AR>(true));
     v.push_back(col_variant<T, 4, 8, 6, AR>(false));
     v.push_back(col_variant<T, 4, 8, 6, AR>(false, true));
+    v.push_back(col_variant<T, 4, 8, 7, AR>(false));
+    v.push_back(col_variant<T, 4, 8, 7, AR>(false, true));
     v.push_back(col_variant<T, 3, 8, 5, AR>(true));
     v.push_back(col_variant<T, 3, 8, 6, AR>(true));
     v.push_back(col_variant<T, 3, 8, 6, AR>(false, true));
