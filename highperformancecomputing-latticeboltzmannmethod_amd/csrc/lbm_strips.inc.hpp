@@ -1,0 +1,420 @@
+// csrc/lbm_strips.inc.hpp — strip halo exchange (RCCL send/recv, in-process groups), the choreography of one launch (edge bands, events, side stream), plan_launch / advance, state initialisation
+// (part of the one host translation unit lbm_hip.hip, which includes it in this place; round 4 split a 2 100-line file by concern)
+// ---- strip halo exchange ----------------------------------------------------------------------------------
+// After a launch has produced the new populations in buf[dst]: my top GR interior rows go to the north neighbour's
+// south ghost rows, my bottom GR interior rows to the south neighbour's north ghost rows, all nine populations
+// (a fused launch recomputes up to two of the neighbour's rows, which needs every population; per lattice update
+// this is the reference's 9 values per edge cell, LBMGrid.h:404-406). Strips always use the row-interleaved layout, in
+// which GR rows x 9 sub-rows are ONE contiguous run of GR*pitch elements: one message per face, no packing.
+// FaceSpans is the single place the offsets and the count are computed; every transport below uses it.
+struct FaceSpans {
+    size_t cnt;       // elements per face message (GR rows x pitch)
+    long top_rows;    // my top GR interior rows      (gy = nyl .. nyl+GR-1)    -> north neighbour's ghost_s
+    long bot_rows;    // my bottom GR interior rows   (gy = GR .. 2GR-1)        -> south neighbour's ghost_n
+    long ghost_n;     // my north ghost rows          (gy = nyl+GR .. nyl+2GR-1)
+    long ghost_s;     // my south ghost rows          (gy = 0 .. GR-1)
+};
+inline FaceSpans face_spans(const lbm_ctx* c) {
+    FaceSpans f;
+    f.cnt = (size_t)GR * c->pitch;
+    f.top_rows = (long)c->nyl * c->pitch;
+    f.bot_rows = (long)GR * c->pitch;
+    f.ghost_n = (long)(c->nyl + GR) * c->pitch;
+    f.ghost_s = 0;
+    return f;
+}
+
+// Transports of ONE context: RCCL send/recv between processes (rank r <-> r-1, r+1), or the test-only loopbacks.
+template <typename T>
+int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
+    if (c->skip_exchange) return LBM_OK;
+    const FaceSpans f = face_spans(c);
+    T* b = static_cast<T*>(c->buf[dst]);
+    const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+    if (c->loopback) {   // test transports: my own edge rows become my ghost rows
+        if (c->layout != 1) return fail(LBM_ERR_COMM, "loopback requires the row-interleaved layout");
+        if (c->loopback == 2) {   // ... through RCCL itself: a one-rank communicator sending to / receiving from rank 0
+            if (!c->comm) return fail(LBM_ERR_COMM, "loopback=2 needs lbm_comm_init(c, 0, 1, id)");
+            NCCLCHK(ncclGroupStart());        // self send/recv pairs match in posting order
+            NCCLCHK(ncclSend(b + f.top_rows, f.cnt, dt, 0, c->comm, s));
+            NCCLCHK(ncclRecv(b + f.ghost_s, f.cnt, dt, 0, c->comm, s));
+            NCCLCHK(ncclSend(b + f.bot_rows, f.cnt, dt, 0, c->comm, s));
+            NCCLCHK(ncclRecv(b + f.ghost_n, f.cnt, dt, 0, c->comm, s));
+            NCCLCHK(ncclGroupEnd());
+            return LBM_OK;
+        }
+        const size_t bytes = f.cnt * sizeof(T);                   // ... or plain device copies on the same stream
+        HIPCHK(hipMemcpyAsync(b + f.ghost_s, b + f.top_rows, bytes, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(b + f.ghost_n, b + f.bot_rows, bytes, hipMemcpyDeviceToDevice, s));
+        return LBM_OK;
+    }
+    if (c->nranks <= 1) return LBM_OK;
+    if (c->layout != 1) return fail(LBM_ERR_COMM, "strips require the row-interleaved layout");
+    NCCLCHK(ncclGroupStart());
+    if (c->rank + 1 < c->nranks) {
+        NCCLCHK(ncclSend(b + f.top_rows, f.cnt, dt, c->rank + 1, c->comm, s));
+        NCCLCHK(ncclRecv(b + f.ghost_n, f.cnt, dt, c->rank + 1, c->comm, s));
+    }
+    if (c->rank > 0) {
+        NCCLCHK(ncclSend(b + f.bot_rows, f.cnt, dt, c->rank - 1, c->comm, s));
+        NCCLCHK(ncclRecv(b + f.ghost_s, f.cnt, dt, c->rank - 1, c->comm, s));
+    }
+    NCCLCHK(ncclGroupEnd());
+    return LBM_OK;
+}
+
+inline hipStream_t exchange_stream(const lbm_ctx* c) { return c->overlap ? c->comm_stream : c->stream; }
+
+// Transports of an in-process GROUP of strips (lbm_group_link): every member's exchange is issued by the one host
+// thread that drives the group, after every member's edge rows have been queued.
+//   peer : each strip PULLS its neighbours' edge rows into its own ghost rows (hipMemcpyPeerAsync over xGMI, a plain
+//          device copy when both strips share a device) on its own exchange stream, behind the neighbour's ev_edge;
+//   rccl : all members' ncclSend/ncclRecv inside ONE ncclGroupStart/End (one communicator per member, ncclCommInitAll).
+// peer transport, one member: pull the neighbours' edge rows of buf[dst] into my ghost rows on my exchange stream
+template <typename T>
+int pull_halos(lbm_ctx** cs, int n, int k, int dst) {
+    lbm_ctx* c = cs[k];
+    if (c->skip_exchange) return LBM_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const FaceSpans f = face_spans(c);
+    T* b = static_cast<T*>(c->buf[dst]);
+    hipStream_t s = exchange_stream(c);
+    const size_t bytes = f.cnt * sizeof(T);
+    auto pull = [&](lbm_ctx* nb, long nb_rows, long my_ghost) -> int {
+        const T* src = static_cast<const T*>(nb->buf[dst]) + nb_rows;
+        HIPCHK(hipStreamWaitEvent(s, nb->ev_edge, 0));            // the neighbour's edge rows of this launch are written
+        if (nb->device == c->device) HIPCHK(hipMemcpyAsync(b + my_ghost, src, bytes, hipMemcpyDeviceToDevice, s));
+        else HIPCHK(hipMemcpyPeerAsync(b + my_ghost, c->device, src, nb->device, bytes, s));
+        return LBM_OK;
+    };
+    if (k > 0) { int rc = pull(cs[k - 1], face_spans(cs[k - 1]).top_rows, f.ghost_s); if (rc) return rc; }
+    if (k + 1 < n) { int rc = pull(cs[k + 1], face_spans(cs[k + 1]).bot_rows, f.ghost_n); if (rc) return rc; }
+    return LBM_OK;
+}
+
+template <typename T>
+int exchange_group(lbm_ctx** cs, int n, int dst) {
+    if (n < 2 || cs[0]->skip_exchange) return LBM_OK;
+    if (cs[0]->group_transport == 1) {
+        const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+        NCCLCHK(ncclGroupStart());
+        for (int k = 0; k < n; ++k) {
+            lbm_ctx* c = cs[k];
+            const FaceSpans f = face_spans(c);
+            T* b = static_cast<T*>(c->buf[dst]);
+            hipStream_t s = exchange_stream(c);
+            if (k + 1 < n) {
+                NCCLCHK(ncclSend(b + f.top_rows, f.cnt, dt, k + 1, c->comm, s));
+                NCCLCHK(ncclRecv(b + f.ghost_n, f.cnt, dt, k + 1, c->comm, s));
+            }
+            if (k > 0) {
+                NCCLCHK(ncclSend(b + f.bot_rows, f.cnt, dt, k - 1, c->comm, s));
+                NCCLCHK(ncclRecv(b + f.ghost_s, f.cnt, dt, k - 1, c->comm, s));
+            }
+        }
+        NCCLCHK(ncclGroupEnd());
+        return LBM_OK;
+    }
+    for (int k = 0; k < n; ++k) {
+        int rc = pull_halos<T>(cs, n, k, dst);
+        if (rc) return rc;
+    }
+    return LBM_OK;
+}
+
+// ---- one launch, in phases --------------------------------------------------------------------------------
+// A launch advances `depth` iterations (1, or 2/3 fused). Strips (a context with internal faces) issue launches in
+// pairs between halo exchanges: KIND_EXTENDED (first of a pair: the strip's rows plus EXT ghost rows per internal
+// face, no exchange afterwards) and KIND_EXCHANGE (a normal launch followed by the exchange of GR rows); without
+// deep halos every launch is KIND_EXCHANGE. KIND_LOCAL: no neighbour to talk to.
+//
+// KIND_EXCHANGE with overlap. The E rows next to each neighbour ("edge bands": E = GR for one iteration,
+// one band of the fused kernel otherwise) contain the GR rows that travel. They are updated by ONE launch on the side
+// stream, followed there by the exchange; the remaining interior rows are updated concurrently on the main stream:
+//   side stream : wait(ev_main: everything queued on the main stream so far) -> edge bands -> record(ev_edge)
+//                 -> exchange -> record(ev_comm)
+//   main stream : record(ev_main) ... wait(ev_edge of the PREVIOUS group) -> interior rows
+// Hazards: edge(n) and interior(n) both read rows the other kind wrote in group n-1 (ev_main / ev_edge); edge(n) reads
+// the ghost rows recv(n-1) wrote and recv(n) overwrites ghost rows edge(n-1) read, send(n) reads what edge(n) wrote,
+// edge(n+1) overwrites rows send(n-1) read (all ordered by the side stream itself); interior(n) overwrites rows of
+// the buffer edge(n-1) read (ev_edge). Interior rows read no ghost row (E >= GR) and write no edge row. Consumers on
+// the main stream (forces, snapshots) first wait for ev_comm (join_comm). In a group with the peer transport a strip's
+// edge rows are additionally read by its NEIGHBOURS' pulls: before they are overwritten the launching stream waits for
+// the neighbours' ev_comm (their last pull).
+// Without overlap the whole launch and the exchange run on the main stream (ev_edge / ev_comm are recorded all the
+// same: the group transports order themselves by them).
+enum { KIND_LOCAL = 0, KIND_EXTENDED = 1, KIND_EXCHANGE = 2 };
+struct Launch { int depth, kind, src, dst, t; };
+
+inline int join_comm(lbm_ctx* c);
+constexpr int EXT = 3;   // rows of each internal face recomputed by the first launch of a pair
+inline bool face_south(const lbm_ctx* c) { return c->p.y_start > 0 || c->loopback; }
+inline bool face_north(const lbm_ctx* c) { return c->p.y_start + c->nyl < c->p.ny || c->loopback; }
+
+template <typename T>
+void launch_depth(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s) {
+    if (depth > 1) launch_fused_rows<T>(c, a, depth, s);
+    else launch_rows<T, MODE_STEP>(c, a, s);
+}
+
+// Decide the next launch of a context that still has `remaining` iterations to go in this call. Fusion: d iterations are
+// fused only when the plan allows it, when none of the iterations t+1 .. t+d-1 is a force-output iteration (their
+// post-collision states never exist in memory) and when at least one more iteration follows inside this call, so that
+// the last launch of every lbm_step call is a single iteration and buf[cur^1] holds the previous iteration's
+// populations (macro snapshot / f_current accessors) — unless "trailing_pair" lifts that rule. The last launch of a call
+// is never the first of a pair, so every call ends with valid ghost rows. Every rank derives the same sequence from
+// (steps_done, remaining, output_frequency). Without a device transport (host-staged halos: the caller exchanges after
+// every call) a call may therefore contain at most two launches.
+inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool strip_logic, Launch* L) {
+    const int t = c->steps_done;
+    int depth = 1;
+    const bool any_face = strip_logic && (face_south(c) || face_north(c));
+    bool deep_plan = false;      // a deep plan exchanges after every launch (no extended first launch of a pair)
+    c->deep_now = false;
+    if (c->fuse > 1) {
+        const int room = remaining - (c->trailing_pair ? 0 : 1);       // iterations a fused launch may take now
+        int dmax = std::min(c->fuse, any_face ? 3 : 4);  // (four: k_step4_tile, no faces)
+        // a deep plan: D iterations while D fit, then the four-/three-/two-iteration tile kernels for what is left
+        // (a strip with faces: its ghost rows go GR deep and are refreshed after every launch, so a deep launch of up to GR
+        // iterations works there too — the register kernel with five / six iterations and the 64x16 LDS shape with six, not the
+        // seven / eight ones)
+        // Whether the faces are EXCHANGED in this call (strip_logic) or not (the plan probe), a context whose rows end at an
+        // internal face has GR rows beyond them and no more: the seven- / eight-iteration shapes would read past the frame.
+        const bool phys_face = face_south(c) || face_north(c);
+        const int deep = (c->deep && (!phys_face || deep_depth(c->deep) <= GR)) ? deep_depth(c->deep) : 0;
+        if (deep) {
+            // `seg` iterations may be fused from here: up to the next force-output iteration (its post-collision state
+            // must exist in memory) and the end of the call. A long segment takes the plan's depth; near its end the
+            // cheapest split into launches of the available depths is taken instead (20 = 7 + 7 + 6 in registers, 6 + 6 + 4 + 4
+            // on an LDS shape, rather than 6 + 6 + 6 + 2: the two- and one-iteration kernels run at half and a third of the
+            // fused rate).
+            const int seg = of > 0 ? std::min(room, of - t % of) : room;
+            // depths the plan's kernel family offers: the register kernel five and six iterations anywhere, seven on a
+            // context without strip faces (a strip's ghost rows go six deep); the LDS shapes their own depth only
+            auto in_family = [&](int d) {
+                if (d == deep) return true;
+                if (!deep_is_col(c->deep)) return false;
+                return d == 5 || d == 6 || (d == 7 && !phys_face);
+            };
+            int fam_min = deep;
+            for (int d = 2; d < deep; ++d) if (in_family(d)) { fam_min = d; break; }
+            dmax = std::min(any_face ? 3 : 4, fam_min - 1);
+            if (seg >= 4 * deep) depth = deep;
+            else if (seg >= 2) {
+                const double* per_it = c->depth_rel;                             // depth 1..4 relative to the deep kernel
+                constexpr double LAUNCH = 0.25;   // what one more launch costs, in iterations of the deep kernel (kernel boundary + a partly filled last round)
+                double best[64];
+                int first[64];
+                best[0] = 0.0; first[0] = 0;
+                for (int r = 1; r <= seg; ++r) {
+                    best[r] = 1e30; first[r] = 1;
+                    for (int d = 1; d <= std::min(r, 8); ++d) {
+                        const bool fam = in_family(d);
+                        if (!fam && d > dmax) continue;
+                        const double cst = best[r - d] + (fam ? 1.0 : per_it[d - 1]) * d + LAUNCH;
+                        if (cst < best[r] - 1e-12 || (d == deep && cst < best[r] + 1e-12)) { best[r] = cst; first[r] = d; }
+                    }
+                }
+                depth = first[seg];
+            }
+            c->deep_now = depth > 1 && in_family(depth);
+            dmax = depth;       // (decided: the generic rule below only confirms it)
+            deep_plan = true;
+        }
+        // A three-iteration plan leaves a one- or two-iteration launch at the end of a call whose length is not a
+        // multiple of three, which runs at half the rate. Where the four-iteration kernel is usable, one (remainder 1)
+        // or two (remainder 2) four-iteration launches absorb it: 20 = 4 + 4 + 3 + 3 + 3 + 3.
+        if (c->fuse == 3 && dmax == 3 && !any_face && of <= 0 && (room % 3 == 1 ? room >= 4 : (room % 3 == 2 && room >= 8)))
+            dmax = 4;
+        for (int d = dmax; d >= 2 && depth == 1; --d) {
+            if (room < d) continue;
+            bool ok = true;
+            for (int j = 1; j < d; ++j) ok = ok && !(of > 0 && (t + j) % of == 0);
+            if (ok) depth = d;
+        }
+    }
+    const bool faces = strip_logic && (face_south(c) || face_north(c));
+    const bool last = remaining - depth <= 0;
+    L->depth = depth; L->src = c->cur; L->dst = c->cur ^ 1; L->t = t;
+    // (an extended launch recomputes EXT ghost rows and leaves GR - EXT valid ones: launches of up to EXT iterations only;
+    // a deep plan with a device transport exchanges after every launch instead)
+    if (faces && c->deep_halo && !last && !c->mid_pair && depth <= EXT && !(deep_plan && transport)) L->kind = KIND_EXTENDED;
+    else {
+        if (faces && !transport && !last)
+            return fail(LBM_ERR_ARG, "a strip with host-staged halos can take at most two launches per lbm_step call "
+                                     "(exchange the edge rows, then call again)");
+        L->kind = transport ? KIND_EXCHANGE : KIND_LOCAL;
+    }
+    return LBM_OK;
+}
+
+// Everything of a launch that precedes its exchange.
+template <typename T>
+int issue_before(lbm_ctx* c, const Launch& L) {
+    KArgs<T> a = make_kargs<T>(c, L.src, L.dst, L.t);
+    const int rev = (c->alternate && (c->launches_total & 1)) ? 1 : 0;
+    if (L.kind == KIND_LOCAL) {
+        a.reverse = rev;
+        launch_depth<T>(c, a, L.depth, c->stream);
+        HIPCHK(hipGetLastError());
+        return LBM_OK;
+    }
+    const int E = c->deep_now ? deep_rows(c, c->deep, L.depth) : L.depth > 1 ? c->pair_ty : GR;   // one tile band
+    if (L.kind == KIND_EXTENDED) {   // all rows of the strip PLUS the EXT ghost rows next to each internal face
+        const int es = face_south(c) ? EXT : 0, en = face_north(c) ? EXT : 0;
+        int e0 = face_south(c) ? E : 0, e1 = face_north(c) ? E : 0;
+        if (c->overlap == 2 && c->comm_issued && e0 + e1 < c->nyl) {
+            // Schedule 2: the exchange that follows the previous launch is still in flight on the side stream. The rows
+            // that do not depend on it start now on the main stream; the bands next to the faces (and the extension)
+            // follow the exchange on the side stream. The next launch waits for ev_edge.
+            a.y_lo = e0; a.y_cnt = c->nyl - e0 - e1; a.reverse = rev;
+            launch_depth<T>(c, a, L.depth, c->stream);
+            HIPCHK(hipGetLastError());
+            KArgs<T> b = make_kargs<T>(c, L.src, L.dst, L.t);
+            b.y_lo = -es; b.y_cnt = e0 + es; b.y_lo2 = c->nyl - e1; b.y_cnt2 = e1 + en;
+            if (b.y_cnt == 0) { b.y_lo = b.y_lo2; b.y_cnt = b.y_cnt2; b.y_cnt2 = 0; }
+            launch_depth<T>(c, b, L.depth, c->comm_stream);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->ev_edge, c->comm_stream));
+            c->ext_split_pending = true;
+            return LBM_OK;
+        }
+        int rc = join_comm(c);       // the last exchange (and the edge bands before it) live on the side stream
+        if (rc) return rc;
+        a.y_lo = -es;
+        a.y_cnt = c->nyl + es + en;
+        a.reverse = rev;
+        launch_depth<T>(c, a, L.depth, c->stream);
+        HIPCHK(hipGetLastError());
+        return LBM_OK;
+    }
+    hipStream_t es = exchange_stream(c);
+    auto wait_for_neighbour_pulls = [&](hipStream_t s) -> int {   // group / peer: my edge rows of buf[dst] may still be being read
+        for (lbm_ctx* nb : {c->nb_south, c->nb_north})
+            if (nb && c->group_transport == 0 && nb->comm_issued) HIPCHK(hipStreamWaitEvent(s, nb->ev_comm, 0));
+        return LBM_OK;
+    };
+    if (c->overlap != 1) {
+        // 0: launch and exchange on the main stream. 2: the launch on the main stream, the exchange on the side stream
+        // behind it (ev_main) — it is the NEXT launch's interior rows that overlap with it.
+        int rc = join_comm(c);       // (2) the edge part of a split extended launch / the exchange of a shallow-halo run
+        if (rc) return rc;
+        rc = wait_for_neighbour_pulls(c->stream);
+        if (rc) return rc;
+        a.reverse = rev;
+        launch_depth<T>(c, a, L.depth, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev_edge, c->stream));
+        if (c->overlap == 2) {
+            HIPCHK(hipEventRecord(c->ev_main, c->stream));
+            HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_main, 0));
+        }
+        return LBM_OK;
+    }
+    const bool has_s = face_south(c), has_n = face_north(c);
+    // (edge bands on the 64x16 LDS tile of one-cell threads with the interior in registers — the shortest edge launch — were
+    // measured: one rank of eight / four / two 8.70 / 11.48 / 17.61 us per iteration against 8.63 / 11.38 / 17.39 for the
+    // register kernel throughout: the interior blocks share the CUs with the edge blocks either way. Not kept.)
+    int e0 = has_s ? E : 0, e1 = has_n ? E : 0;
+    if (e0 + e1 >= c->nyl) { e0 = c->nyl; e1 = 0; }          // short strip: everything is edge
+    HIPCHK(hipEventRecord(c->ev_main, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_main, 0));
+    if (c->comm_issued) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_edge, 0));   // ev_edge still is the previous group's
+    int rc = wait_for_neighbour_pulls(es);
+    if (rc) return rc;
+    a.reverse = 0;
+    a.y_lo = 0; a.y_cnt = e0; a.y_lo2 = c->nyl - e1; a.y_cnt2 = e1;
+    if (e0 == 0) { a.y_lo = a.y_lo2; a.y_cnt = e1; a.y_cnt2 = 0; }
+    launch_depth<T>(c, a, L.depth, c->comm_stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev_edge, c->comm_stream));
+    c->edge_rows[0] = e0; c->edge_rows[1] = e1;
+    return LBM_OK;
+}
+
+// Everything of a launch that follows its exchange, and the bookkeeping.
+template <typename T>
+int issue_after(lbm_ctx* c, const Launch& L) {
+    if (L.kind == KIND_EXCHANGE) {
+        HIPCHK(hipEventRecord(c->ev_comm, exchange_stream(c)));
+        c->comm_issued = true;
+        if (c->overlap == 1) {
+            const int e0 = c->edge_rows[0], e1 = c->edge_rows[1];
+            if (c->nyl - e0 - e1 > 0) {
+                KArgs<T> a = make_kargs<T>(c, L.src, L.dst, L.t);
+                a.y_lo = e0; a.y_cnt = c->nyl - e0 - e1;
+                a.reverse = (c->alternate && (c->launches_total & 1)) ? 1 : 0;
+                launch_depth<T>(c, a, L.depth, c->stream);
+                HIPCHK(hipGetLastError());
+            }
+        }
+    }
+    c->mid_pair = (L.kind == KIND_EXTENDED);
+    c->cur = L.dst;
+    c->steps_done = L.t + L.depth;
+    c->launches_total++;
+    c->last_was_pair = L.depth > 1;
+    c->restored = false;
+    return LBM_OK;
+}
+
+// Advance ONE context by up to `remaining` iterations with one launch; returns the iterations taken (1..3) or <0.
+template <typename T>
+int advance(lbm_ctx* c, int remaining, int of, bool transport, bool strip_logic = true) {
+    Launch L;
+    int rc = plan_launch(c, remaining, of, transport, strip_logic, &L);
+    if (rc) return rc;
+    rc = issue_before<T>(c, L);
+    if (rc) return rc;
+    if (L.kind == KIND_EXCHANGE) {
+        rc = exchange_rccl<T>(c, L.dst, exchange_stream(c));
+        if (rc) return rc;
+    }
+    rc = issue_after<T>(c, L);
+    if (rc) return rc;
+    return L.depth;
+}
+
+// Make everything issued so far (both streams) visible to work queued on the compute stream afterwards.
+inline int join_comm(lbm_ctx* c) {
+    if (c->ext_split_pending) {   // overlap 2: the edge bands of the last extended launch (queued behind the exchange)
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_edge, 0));
+        c->ext_split_pending = false;
+    }
+    if (c->comm_issued) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+    return LBM_OK;
+}
+
+template <typename T>
+int init_state(lbm_ctx* c) {
+    InitArgs<T> ia;
+    ia.a = static_cast<T*>(c->buf[0]);
+    ia.b = static_cast<T*>(c->buf[1]);
+    ia.plane = (long)c->plane; ia.pitch = c->pitch; ia.xoff = c->xoff;
+    ia.nx = c->nx; ia.ny_loc = c->nyl; ia.ny_glob = c->p.ny; ia.y_start = c->p.y_start;
+    ia.cyl_x = c->cyl_x; ia.cyl_y = c->cyl_y; ia.cyl_r2 = (double)(c->cyl_r * c->cyl_r);
+    for (int i = 0; i < Q; ++i) ia.feq_in[i] = (T)c->feq_in[i];
+    ia.solid_count = c->d_solid_count;
+    HIPCHK(hipMemsetAsync(c->d_solid_count, 0, sizeof(int), c->stream));
+    dim3 grid((c->nx + 2 + 255) / 256, c->nyl + 2 * GR), block(256);
+    hipLaunchKernelGGL((k_init<T>), grid, block, 0, c->stream, ia);
+    HIPCHK(hipGetLastError());
+    // collision_step of iteration 0: initial state (buf 0) -> P_0 (buf 1)
+    int rc = launch_step<T>(c, 0, 1, 0, MODE_COLLIDE_ONLY, c->stream);
+    if (rc) return rc;
+    c->cur = 1;
+    c->steps_done = 0;
+    return LBM_OK;
+}
+
+inline void free_buffers(lbm_ctx* c) {
+    for (int k = 0; k < 2; ++k)
+        if (c->buf[k]) { (void)hipFree(c->buf[k]); c->buf[k] = nullptr; }
+}
+inline int alloc_buffers(lbm_ctx* c) {
+    free_buffers(c);
+    HIPCHK(hipMalloc(&c->buf[0], buffer_bytes(c)));
+    HIPCHK(hipMalloc(&c->buf[1], buffer_bytes(c)));
+    return LBM_OK;
+}
+
