@@ -275,9 +275,6 @@ __device__ __forceinline__ void bgk_collide(T (&f)[Q], T tau_inv) {
         const T t3 = T(3.0) * cu, t45 = (T(4.5) * cu) * cu;
         relax(f[i], wr, ((T(1.0) + t3) + t45) - c15);
         relax(f[ib], wr, ((T(1.0) - t3) + t45) - c15);
-#ifdef LBM_STRICT_PAIR_BARRIER
-        __builtin_amdgcn_sched_barrier(0);
-#endif
     };
     pair(1, 3, ux, wr1);              // c1 = (1,0),  c3 = (-1,0)
     pair(2, 4, uy, wr1);              // c2 = (0,1),  c4 = (0,-1)
