@@ -38,6 +38,22 @@ def candidates(lbm, nx, ny, precision, arith):
     return out
 
 
+def unprofiled(nx, ny, prec, arith, options, re_):
+    """The same probe WITHOUT a counter pass around it: HIP-event time of this plan on this box (600 iterations)."""
+    import re
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py"), "--nx", str(nx), "--ny", str(ny), "--re", repr(re_), "--precision", prec,
+           "--arith", str(arith), "--plan", options, "--steps", "120", "--reps", "5" if nx * ny <= (1 << 24) else "2", "--warm", "2"]
+    try:
+        out = subprocess.run(cmd, cwd="/tmp", timeout=300, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        m = re.search(r'^\{"probe".*$', out.stdout, re.M)
+        p = json.loads(m.group(0))
+        us = p["ms_per_iteration"] * 1e3
+        return {"us_per_iteration_unprofiled": round(us, 3), "mlups_unprofiled": round(nx * ny / us, 1)}
+    except Exception as e:
+        return {"us_per_iteration_unprofiled": None, "mlups_unprofiled": None, "timing_error": str(e)[:120]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "traffic.json"))
@@ -68,9 +84,11 @@ def main():
                 if keep:
                     os.makedirs(keep, exist_ok=True)
                 ent, note = bench.live_counters(nx, ny, prec, arith, c["options"], 120, re_, keep_dir=keep)
+                timing = unprofiled(nx, ny, prec, arith, c["options"], re_)
                 if ent is None:
                     print(f"[collect] {key} {c['kernel']} ({c['layout']}): FAILED: {note}", flush=True)
                     continue
+                ent.update(timing)
                 ent.update(layout=c["layout"], plan=c["name"], plan_options=c["options"], arithmetic="contracted" if arith else "strict",
                            source="profiles/traffic.json (tools/collect_live_traffic.py)",
                            algorithmic_bytes_per_launch=int(nx * ny * bench.BYTES_PER_LUP[prec] * ent["iterations_per_launch"]))

@@ -43,16 +43,21 @@ def main():
         c.initialise()
         c.set_option("timing", 1)
         launches = iters = 0
-        for _ in range(a.warm + a.reps):
+        ms = 0.0
+        for k in range(a.warm + a.reps):
             c.step(a.steps, 0)
             c.sync()
-            _, nl, ni = c.last_step_stats()
+            t, nl, ni = c.last_step_stats()
             launches += nl
             iters += ni
+            if k >= a.warm:
+                ms += t
         bad = c.first_unstable_step()
         print(json.dumps({"probe": True, "kernel": c.kernel_name(), "plan": c.plan(), "plan_options": c.plan_options(),
                           "build_id": lbm.build_id(), "calls": a.warm + a.reps, "steps_per_call": a.steps,
-                          "launches": launches, "iterations": iters, "unstable": bad}), flush=True)
+                          "launches": launches, "iterations": iters, "unstable": bad,
+                          # HIP-event time of the counted calls (meaningful only when this program runs WITHOUT a counter pass around it)
+                          "ms_per_iteration": ms / max(1, a.reps * a.steps)}), flush=True)
     return 0 if bad == -1 else 1
 
 
