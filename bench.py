@@ -159,7 +159,10 @@ PMC_GROUPS = (("FETCH_SIZE",), ("WRITE_SIZE",),
 _INIT_KERNEL = re.compile(r"k_step_site<\w+,1,|k_step_vec<\w+,\d+,1,")      # the collide-only launch of lbm_initialise
 
 
-def live_counters(nx, ny, precision, arith, plan_options, steps, re_number=200.0, timeout=240, keep_dir=None):
+_LIVE_BROKEN = []      # why the live passes were given up in this run, if they were (one failure: no second attempt, no second timeout)
+
+
+def live_counters(nx, ny, precision, arith, plan_options, steps, re_number=200.0, timeout=120, keep_dir=None):
     """The counter passes of THIS binary on THIS plan, taken now: tools/pmc_probe.py (same grid, plan pinned through
     lbm_plan_options, the bench's own lbm_step(steps) calls) is run as a child under `rocprofv3 --pmc`, one pass per counter
     group (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950). Returns (entry, note) or (None, why)."""
@@ -167,8 +170,11 @@ def live_counters(nx, ny, precision, arith, plan_options, steps, re_number=200.0
     import csv
     import shutil
     import tempfile
+    if _LIVE_BROKEN:
+        return None, "not attempted again: " + _LIVE_BROKEN[0]
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
+        _LIVE_BROKEN.append("rocprofv3 not found")
         return None, "rocprofv3 not found"
     probe_steps = steps if steps <= 240 else 120
     reps, warm = (6, 1) if nx * ny <= (1 << 24) else (2, 1)
@@ -184,10 +190,12 @@ def live_counters(nx, ny, precision, arith, plan_options, steps, re_number=200.0
             out = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                  start_new_session=True)
         except subprocess.TimeoutExpired:
-            return None, f"counter pass {group[0]} timed out after {timeout} s"
+            _LIVE_BROKEN.append(f"counter pass {group[0]} timed out after {timeout} s")
+            return None, _LIVE_BROKEN[0]
         m = re.search(r'^\{"probe".*$', out.stdout, re.M)
         if out.returncode != 0 or not m:
-            return None, f"counter pass {group[0]} failed (rc {out.returncode}): {(out.stderr or out.stdout)[-200:]}"
+            _LIVE_BROKEN.append(f"counter pass {group[0]} failed (rc {out.returncode}): {(out.stderr or out.stdout)[-200:]}")
+            return None, _LIVE_BROKEN[0]
         probe = json.loads(m.group(0))
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if not files:

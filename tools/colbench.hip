@@ -100,7 +100,7 @@ Variant<T> col_variant(bool nt, bool alt = false, int persist = 0) {
     snprintf(nm, sizeof(nm), "col R=%d NW=%d D=%d %s %s p%d", R, NW, D, nt ? "nt" : "  ", alt ? "alt" : "", persist);
     return {nm, D, [=](Lattice<T>& L) {
         constexpr int OW = 64 - 2 * (D - 1), OH = R * NW - 2 * (D - 1);
-        const int nb = ((L.nx + OW - 1) / OW) * ((L.ny + OH - 1) / OH);
+        int nb = ((L.nx + OW - 1) / OW) * ((L.ny + OH - 1) / OH);
         (void)persist;
         dim3 grid((nb + 7) / 8 * 8);
         KArgs<T> a = L.args(L.t);
