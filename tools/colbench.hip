@@ -20,7 +20,8 @@ using namespace lbmk;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
 static bool g_map = false;
-static int g_ntl = 0;       // --ntl 1: non-temporal level-1 loads in the register kernel
+static int g_ntl = 0;
+static int g_pad = 0;       // --pad N: N x 128 B added to every sub-row (channel-mapping experiment)       // --ntl 1: non-temporal level-1 loads in the register kernel
 template <typename T>
 struct Lattice {
     int nx, ny, pitch, xoff;
@@ -37,7 +38,7 @@ struct Lattice {
     Lattice(int nx_, int ny_) : nx(nx_), ny(ny_) {
         const int per128 = 128 / sizeof(T);
         xoff = per128;
-        const int pitch0 = (xoff + nx + 1 + per128 - 1) / per128 * per128;
+        const int pitch0 = (xoff + nx + 1 + per128 - 1) / per128 * per128 + g_pad * per128;
         plane = pitch0; pitch = Q * pitch0; total = (size_t)pitch * (ny + 2 * GR);     // row-interleaved
         CK(hipMalloc(&A, (total + 64) * sizeof(T)));
         CK(hipMalloc(&B, (total + 64) * sizeof(T)));
@@ -315,6 +316,7 @@ int main(int argc, char** argv) {
         else if (k == "--filter") filter = argv[++i];
         else if (k == "--prof") profdir = argv[++i];
         else if (k == "--ntl") g_ntl = atoi(argv[++i]);
+        else if (k == "--pad") g_pad = atoi(argv[++i]);
         else if (k == "--stagger") g_stagger = atoi(argv[++i]);
         else if (k == "--map") { g_map = true; mnx = atoi(argv[++i]); mny = atoi(argv[++i]); mlaunch = atoi(argv[++i]); }
     }
