@@ -137,7 +137,8 @@ struct lbm_ctx {
     int num_cus = 256;   // compute units of the device (what counts as a small grid: one round of blocks)
     int loopback = 0;    // TEST ONLY: the strip is its own north and south neighbour (exercises the overlap choreography):
                          // 1 = device copies, 2 = RCCL send/recv to self on a one-rank communicator
-    int deep_halo = 1;       // strips: one exchange of GR rows per TWO launches (the first launch of a pair is extended)
+    int deep_halo = 1;       // strips: 1 = one exchange of six rows per TWO launches of up to three iterations (the first launch of a pair is
+                             // extended); deep plans exchange after every launch. 2 = deep plans too: twelve rows per two launches of up to six
     int trailing_pair = 0;   // allow an lbm_step call to END on a fused launch (host-staged strips)
     bool mid_pair = false;        // the last launch was the extended first launch of a pair (no exchange after it)
     bool last_was_pair = false;   // the last launch fused several iterations: buf[cur^1] is older than steps_done-1
@@ -182,6 +183,6 @@ struct lbm_ctx {
     long graph_replays = 0;
     char graph_note[128] = "";       // why the graph path was given up, if it was
     // host-staged halo staging (device side)
-    double* d_halo = nullptr;  // 4 faces-in-flight x [GR][9][nx] doubles
+    double* d_halo = nullptr;  // 4 faces-in-flight x [HR1][9][nx] doubles
 };
 

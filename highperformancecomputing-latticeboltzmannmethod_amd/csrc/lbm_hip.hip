@@ -186,7 +186,7 @@ int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
         HIPTRY(hipMemcpy(c->d_feq, c->feq_in, Q * sizeof(double), hipMemcpyHostToDevice));
     }
     HIPTRY(hipMalloc(&c->d_force_log, 3 * sizeof(double) * c->log_cap));
-    HIPTRY(hipMalloc(&c->d_halo, 4 * GR * Q * sizeof(double) * (size_t)c->nx));
+    HIPTRY(hipMalloc(&c->d_halo, 4 * HR1 * Q * sizeof(double) * (size_t)c->nx));
     HIPTRY(hipMalloc(&c->d_red, 64 * sizeof(double)));
 #undef HIPTRY
     *out = c;
@@ -388,7 +388,7 @@ int lbm_comm_init(lbm_ctx* c, int rank, int nranks, const void* id128) {
     NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
     c->rank = rank;
     c->nranks = nranks;
-    if (nranks > 1 && c->nyl < 2 * GR) return fail(LBM_ERR_ARG, "a strip with neighbours needs at least %d rows", 2 * GR);
+    if (nranks > 1 && c->nyl < 2 * HR1) return fail(LBM_ERR_ARG, "a strip with neighbours needs at least %d rows", 2 * HR1);
     return LBM_OK;
 }
 
@@ -448,7 +448,7 @@ int lbm_group_link(lbm_ctx** cs, int n, int transport) {
             return fail(LBM_ERR_ARG, "the strips of a group must share nx, ny and the precision");
         const int expect = k == 0 ? 0 : cs[k - 1]->p.y_start + cs[k - 1]->nyl;
         if (c->p.y_start != expect) return fail(LBM_ERR_ARG, "strip %d starts at row %d, expected %d (bottom to top, contiguous)", k, c->p.y_start, expect);
-        if (n > 1 && c->nyl < 2 * GR) return fail(LBM_ERR_ARG, "a strip with neighbours needs at least %d rows", 2 * GR);
+        if (n > 1 && c->nyl < 2 * HR1) return fail(LBM_ERR_ARG, "a strip with neighbours needs at least %d rows", 2 * HR1);
     }
     if (cs[n - 1]->p.y_start + cs[n - 1]->nyl != cs[0]->p.ny) return fail(LBM_ERR_ARG, "the strips do not cover all %d rows", cs[0]->p.ny);
     if (n == 1) return LBM_OK;
@@ -608,7 +608,7 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "trailing_pair") c->trailing_pair = (int)value ? 1 : 0;
     else if (k == "xcd") c->xcd = (int)value ? 1 : 0;
     else if (k == "arith") { if (value != 0 && value != 1) return fail(LBM_ERR_ARG, "arith must be 0 (strict) or 1 (contracted)"); c->arith = (int)value; }
-    else if (k == "deep_halo") { c->deep_halo = (int)value ? 1 : 0; c->deep_pinned = true; }
+    else if (k == "deep_halo") { if (value < 0 || value > 2) return fail(LBM_ERR_ARG, "deep_halo must be 0, 1 or 2"); c->deep_halo = (int)value; c->deep_pinned = true; }
     else if (k == "skip_exchange") c->skip_exchange = (int)value ? 1 : 0;
     else if (k == "group_threads") c->group_threads = (int)value ? 1 : 0;
     else if (k == "graph") { if (value < 0 || value > 2) return fail(LBM_ERR_ARG, "graph must be 0, 1 or 2"); c->use_graph = (int)value; }

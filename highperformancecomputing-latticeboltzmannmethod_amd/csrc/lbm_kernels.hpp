@@ -5,7 +5,7 @@
 //
 //     plane i, local row gy in [0, ny_loc+2*GR), column col:   base[i*plane + gy*pitch + col]
 //     interior cell (x, y)  <->  gy = y+GR, col = xoff + x      (xoff*sizeof(T) is a multiple of 128 B)
-// GR = 6 ghost rows on each side (a strip exchanges its six edge rows once per launch of up to six fused iterations, or once
+// GR = 12 ghost rows on each side, of which a strip exchanges six (once per launch of up to six fused iterations, or once
 // per TWO launches of up to three: the first launch of such a pair also updates three ghost rows per internal face,
 // redundantly with the neighbour, so that the second one finds valid inputs); one ghost column on each side.
 // The two strides describe either of two layouts chosen by the host (lbm_hip.hip, "plan"):
@@ -45,8 +45,11 @@
 namespace lbmk {
 
 constexpr int Q = 9;
-constexpr int GR = 6;   // ghost rows below and above the strip: two launches of up to three iterations each between
-                        // halo exchanges (the first one recomputes three of the neighbour's rows on each side)
+constexpr int GR = 12;  // ghost rows ALLOCATED below and above the strip (the frame every kernel addresses rows by: gy = y + GR)
+constexpr int HR1 = 6;  // ghost rows a strip's halo exchange refreshes per face (LBM_HALO_ROWS): one launch of up to six fused
+                        // iterations, or two of up to three (the first of the pair recomputes three of the neighbour's rows), between
+                        // exchanges. With "deep_halo" 2 (round 4) a deep plan exchanges all GR = 12 rows once per TWO launches of up to six
+                        // iterations each: the first launch of such a pair also updates the six ghost rows next to each internal face.
 // LBMConfig.h:13-34 — direction numbering is observable through f_current(x,y,i), keep it.
 __host__ __device__ constexpr int cx(int i) { constexpr int v[Q] = {0, 1, 0, -1, 0, 1, -1, -1, 1}; return v[i]; }
 __host__ __device__ constexpr int cy(int i) { constexpr int v[Q] = {0, 0, 1, 0, -1, 1, 1, -1, -1}; return v[i]; }

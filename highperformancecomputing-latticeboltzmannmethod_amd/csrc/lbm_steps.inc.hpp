@@ -28,7 +28,7 @@ inline bool graph_wanted(const lbm_ctx* c, int remaining, int of, bool transport
     // one-rank communicator sending to itself captures and replays fine): a multi-rank run takes the graph path only when
     // asked to ("graph" 2) — a refused capture falls back, a hang in an untested collective path would not.
     if (c->nranks > 1 && c->use_graph < 2) return false;
-    if (!c->deep || deep_depth(c->deep) > GR || c->mid_pair || c->overlap == 2) return false;
+    if (!c->deep || deep_depth(c->deep) > HR1 || c->mid_pair || c->overlap == 2) return false;      // (pairs of launches: four groups = two whole pairs)
     if (!(face_south(c) || face_north(c))) return false;
     const int depth = deep_depth(c->deep), iters = GRAPH_GROUPS * depth;
     if (remaining < iters + 4 * depth + 1) return false;                       // (plan_launch splits the END of a segment differently)
@@ -297,16 +297,16 @@ int do_populations(lbm_ctx* c, int which, double* aos) {
 template <typename T>
 int do_halo_export(lbm_ctx* c, double* south_out, double* north_out) {
     const T* base = static_cast<const T*>(c->buf[c->cur]);
-    const size_t n = (size_t)GR * Q * c->nx;
-    dim3 grid((c->nx + 255) / 256, GR * Q), block(256);
-    if (south_out) {   // my bottom GR interior rows
+    const size_t n = (size_t)HR1 * Q * c->nx;
+    dim3 grid((c->nx + 255) / 256, HR1 * Q), block(256);
+    if (south_out) {   // my bottom HR1 interior rows
         hipLaunchKernelGGL((k_halo_pack<T>), grid, block, 0, c->stream, base, (long)c->plane, c->pitch, c->xoff, c->nx, GR,
                            c->d_halo);
         HIPCHK(hipMemcpyAsync(south_out, c->d_halo, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    if (north_out) {   // my top GR interior rows
+    if (north_out) {   // my top HR1 interior rows
         hipLaunchKernelGGL((k_halo_pack<T>), grid, block, 0, c->stream, base, (long)c->plane, c->pitch, c->xoff, c->nx,
-                           c->nyl, c->d_halo + n);
+                           c->nyl + GR - HR1, c->d_halo + n);
         HIPCHK(hipMemcpyAsync(north_out, c->d_halo + n, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -316,14 +316,14 @@ int do_halo_export(lbm_ctx* c, double* south_out, double* north_out) {
 template <typename T>
 int do_halo_import(lbm_ctx* c, const double* south_in, const double* north_in) {
     T* base = static_cast<T*>(c->buf[c->cur]);
-    const size_t n = (size_t)GR * Q * c->nx;
-    dim3 grid((c->nx + 255) / 256, GR * Q), block(256);
-    if (south_in) {    // -> south ghost rows gy = 0 .. GR-1
+    const size_t n = (size_t)HR1 * Q * c->nx;
+    dim3 grid((c->nx + 255) / 256, HR1 * Q), block(256);
+    if (south_in) {    // -> south ghost rows gy = GR-HR1 .. GR-1
         HIPCHK(hipMemcpyAsync(c->d_halo + 2 * n, south_in, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL((k_halo_unpack<T>), grid, block, 0, c->stream, base, (long)c->plane, c->pitch, c->xoff, c->nx, 0,
+        hipLaunchKernelGGL((k_halo_unpack<T>), grid, block, 0, c->stream, base, (long)c->plane, c->pitch, c->xoff, c->nx, GR - HR1,
                            c->d_halo + 2 * n);
     }
-    if (north_in) {    // -> north ghost rows gy = nyl+GR .. nyl+2GR-1
+    if (north_in) {    // -> north ghost rows gy = nyl+GR .. nyl+GR+HR1-1
         HIPCHK(hipMemcpyAsync(c->d_halo + 3 * n, north_in, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL((k_halo_unpack<T>), grid, block, 0, c->stream, base, (long)c->plane, c->pitch, c->xoff, c->nx,
                            c->nyl + GR, c->d_halo + 3 * n);

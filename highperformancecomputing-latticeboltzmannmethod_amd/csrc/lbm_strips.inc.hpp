@@ -7,20 +7,27 @@
 // this is the reference's 9 values per edge cell, LBMGrid.h:404-406). Strips always use the row-interleaved layout, in
 // which GR rows x 9 sub-rows are ONE contiguous run of GR*pitch elements: one message per face, no packing.
 // FaceSpans is the single place the offsets and the count are computed; every transport below uses it.
+// rows per face and exchange / rows of each internal face the first launch of a pair recomputes: six and three, or — a deep plan
+// with "deep_halo" 2 — twelve and six
+inline bool device_transport(const lbm_ctx* c) { return c->group_n > 1 || (c->comm && c->nranks > 1) || c->loopback; }
+inline bool deep_pairs(const lbm_ctx* c) { return c->deep && deep_depth(c->deep) <= HR1 && c->deep_halo == 2 && device_transport(c); }
+inline int halo_rows(const lbm_ctx* c) { return deep_pairs(c) ? 2 * HR1 : HR1; }
+inline int ext_rows(const lbm_ctx* c) { return halo_rows(c) / 2; }
 struct FaceSpans {
-    size_t cnt;       // elements per face message (GR rows x pitch)
-    long top_rows;    // my top GR interior rows      (gy = nyl .. nyl+GR-1)    -> north neighbour's ghost_s
-    long bot_rows;    // my bottom GR interior rows   (gy = GR .. 2GR-1)        -> south neighbour's ghost_n
-    long ghost_n;     // my north ghost rows          (gy = nyl+GR .. nyl+2GR-1)
-    long ghost_s;     // my south ghost rows          (gy = 0 .. GR-1)
+    size_t cnt;       // elements per face message (halo_rows x pitch)
+    long top_rows;    // my top HR interior rows      (gy = nyl+GR-HR .. nyl+GR-1)   -> north neighbour's ghost_s
+    long bot_rows;    // my bottom HR interior rows   (gy = GR .. GR+HR-1)           -> south neighbour's ghost_n
+    long ghost_n;     // my north ghost rows          (gy = nyl+GR .. nyl+GR+HR-1)
+    long ghost_s;     // my south ghost rows          (gy = GR-HR .. GR-1)
 };
 inline FaceSpans face_spans(const lbm_ctx* c) {
     FaceSpans f;
-    f.cnt = (size_t)GR * c->pitch;
-    f.top_rows = (long)c->nyl * c->pitch;
+    const int hr = halo_rows(c);
+    f.cnt = (size_t)hr * c->pitch;
+    f.top_rows = (long)(c->nyl + GR - hr) * c->pitch;
     f.bot_rows = (long)GR * c->pitch;
     f.ghost_n = (long)(c->nyl + GR) * c->pitch;
-    f.ghost_s = 0;
+    f.ghost_s = (long)(GR - hr) * c->pitch;
     return f;
 }
 
@@ -124,7 +131,7 @@ int exchange_group(lbm_ctx** cs, int n, int dst) {
 
 // ---- one launch, in phases --------------------------------------------------------------------------------
 // A launch advances `depth` iterations (1, or 2/3 fused). Strips (a context with internal faces) issue launches in
-// pairs between halo exchanges: KIND_EXTENDED (first of a pair: the strip's rows plus EXT ghost rows per internal
+// pairs between halo exchanges: KIND_EXTENDED (first of a pair: the strip's rows plus ext_rows ghost rows per internal
 // face, no exchange afterwards) and KIND_EXCHANGE (a normal launch followed by the exchange of GR rows); without
 // deep halos every launch is KIND_EXCHANGE. KIND_LOCAL: no neighbour to talk to.
 //
@@ -147,7 +154,6 @@ enum { KIND_LOCAL = 0, KIND_EXTENDED = 1, KIND_EXCHANGE = 2 };
 struct Launch { int depth, kind, src, dst, t; };
 
 inline int join_comm(lbm_ctx* c);
-constexpr int EXT = 3;   // rows of each internal face recomputed by the first launch of a pair
 inline bool face_south(const lbm_ctx* c) { return c->p.y_start > 0 || c->loopback; }
 inline bool face_north(const lbm_ctx* c) { return c->p.y_start + c->nyl < c->p.ny || c->loopback; }
 
@@ -181,7 +187,7 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
         // Whether the faces are EXCHANGED in this call (strip_logic) or not (the plan probe), a context whose rows end at an
         // internal face has GR rows beyond them and no more: the seven- / eight-iteration shapes would read past the frame.
         const bool phys_face = face_south(c) || face_north(c);
-        const int deep = (c->deep && (!phys_face || deep_depth(c->deep) <= GR)) ? deep_depth(c->deep) : 0;
+        const int deep = (c->deep && (!phys_face || deep_depth(c->deep) <= HR1)) ? deep_depth(c->deep) : 0;
         if (deep) {
             // `seg` iterations may be fused from here: up to the next force-output iteration (its post-collision state
             // must exist in memory) and the end of the call. A long segment takes the plan's depth; near its end the
@@ -236,9 +242,11 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
     const bool faces = strip_logic && (face_south(c) || face_north(c));
     const bool last = remaining - depth <= 0;
     L->depth = depth; L->src = c->cur; L->dst = c->cur ^ 1; L->t = t;
-    // (an extended launch recomputes EXT ghost rows and leaves GR - EXT valid ones: launches of up to EXT iterations only;
+    // (an extended launch recomputes ext_rows ghost rows and leaves as many valid ones: launches of up to ext_rows iterations only;
     // a deep plan with a device transport exchanges after every launch instead)
-    if (faces && c->deep_halo && !last && !c->mid_pair && depth <= EXT && !(deep_plan && transport)) L->kind = KIND_EXTENDED;
+    // (deep plans pair up with "deep_halo" 2 only, and only with a device transport: host-staged halos carry six rows)
+    const bool pairs = c->deep_halo && (deep_plan && transport ? deep_pairs(c) : depth <= HR1 / 2);
+    if (faces && pairs && !last && !c->mid_pair && depth <= ext_rows(c)) L->kind = KIND_EXTENDED;
     else {
         if (faces && !transport && !last)
             return fail(LBM_ERR_ARG, "a strip with host-staged halos can take at most two launches per lbm_step call "
@@ -259,9 +267,9 @@ int issue_before(lbm_ctx* c, const Launch& L) {
         HIPCHK(hipGetLastError());
         return LBM_OK;
     }
-    const int E = c->deep_now ? deep_rows(c, c->deep, L.depth) : L.depth > 1 ? c->pair_ty : GR;   // one tile band
-    if (L.kind == KIND_EXTENDED) {   // all rows of the strip PLUS the EXT ghost rows next to each internal face
-        const int es = face_south(c) ? EXT : 0, en = face_north(c) ? EXT : 0;
+    const int E = c->deep_now ? deep_rows(c, c->deep, L.depth) : L.depth > 1 ? c->pair_ty : HR1;   // one tile band (>= the rows that travel: see below)
+    if (L.kind == KIND_EXTENDED) {   // all rows of the strip PLUS the ext_rows ghost rows next to each internal face
+        const int es = face_south(c) ? ext_rows(c) : 0, en = face_north(c) ? ext_rows(c) : 0;
         int e0 = face_south(c) ? E : 0, e1 = face_north(c) ? E : 0;
         if (c->overlap == 2 && c->comm_issued && e0 + e1 < c->nyl) {
             // Schedule 2: the exchange that follows the previous launch is still in flight on the side stream. The rows

@@ -186,9 +186,9 @@ int tune_strip_schedule(lbm_ctx* c) {
     auto describe = [&](const char* how, int tried, double us_per_it) {
         // iterations between two exchanges: a deep launch (up to GR iterations) exchanges after every launch; the
         // three-iteration plans after every launch, or after every second one with the deep halo
-        const bool deep_launches = c->deep && deep_depth(c->deep) <= GR;
-        const int its = deep_launches ? deep_depth(c->deep) : std::min(c->fuse, 3) * (c->deep_halo ? 2 : 1);
-        const double face_bytes = (double)GR * c->pitch * c->esize;
+        const bool deep_launches = c->deep && deep_depth(c->deep) <= HR1;
+        const int its = deep_launches ? deep_depth(c->deep) * (deep_pairs(c) ? 2 : 1) : std::min(c->fuse, 3) * (c->deep_halo ? 2 : 1);
+        const double face_bytes = (double)halo_rows(c) * c->pitch * c->esize;
         int n = snprintf(c->sched_desc, sizeof(c->sched_desc), "overlap=%d deep_halo=%d (%s", c->overlap, c->deep_halo, how);
         if (tried > 0 && n > 0 && n < (int)sizeof(c->sched_desc))
             n += snprintf(c->sched_desc + n, sizeof(c->sched_desc) - n, " of %d measured, %.2f us/iteration", tried, us_per_it);
@@ -205,7 +205,7 @@ int tune_strip_schedule(lbm_ctx* c) {
         // call fails on every rank alike (ranks with different pins ran different numbers of collective trials and
         // the first multi-process lbm_initialise hung in RCCL instead of returning an error).
         double v[5];
-        strip_pins_pack(c->tune && c->nyl >= 4 * GR, c->overlap_pinned, c->overlap, c->deep_pinned, c->deep_halo, v);
+        strip_pins_pack(c->tune && c->nyl >= 4 * HR1, c->overlap_pinned, c->overlap, c->deep_pinned, c->deep_halo, v);
         int rc = allreduce_doubles(c, v, 5, 2);      // MIN
         if (rc) return rc;
         int go = 0, po = 0, pd = 0, ov = c->overlap, dh = c->deep_halo;
@@ -220,8 +220,18 @@ int tune_strip_schedule(lbm_ctx* c) {
     c->trailing_pair = 1;
     constexpr int WARM = 60, TIMED = 240;      // (the warm-up is long enough to take the one-off graph capture of a schedule)
     auto trial = [&](int o, int d, double* worst_ms) -> int {
+        const int rows_before = halo_rows(c);
         c->overlap = o; c->deep_halo = d;
-        int rc = do_steps<T>(&c, 1, WARM, 0);
+        int rc = LBM_OK;
+        if (halo_rows(c) != rows_before) {      // the schedule on trial refreshes a deeper ghost frame: fill it before its first launch reads it
+            rc = join_comm(c);
+            if (rc) return rc;
+            rc = exchange_rccl<T>(c, c->cur, c->stream);
+            if (rc) return rc;
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->mid_pair = false;
+        }
+        rc = do_steps<T>(&c, 1, WARM, 0);
         if (rc) return rc;
         rc = join_comm(c);
         if (rc) return rc;
@@ -237,7 +247,11 @@ int tune_strip_schedule(lbm_ctx* c) {
         *worst_ms = (double)ms;
         return allreduce_doubles(c, worst_ms, 1, 1);   // MAX over the ranks: the job advances at the pace of its slowest strip
     };
-    static const int variants[5][2] = {{1, 1}, {0, 1}, {2, 1}, {1, 0}, {0, 0}};   // (overlap, deep_halo); 2 needs the deep halo
+    // (overlap, deep_halo); overlap 2 needs launches in pairs. A deep plan exchanges after every launch whether deep_halo is 0 or 1,
+    // so its second half of the list is the round-4 schedule instead: twelve rows per TWO launches of six iterations (deep_halo 2)
+    static const int shallow[5][2] = {{1, 1}, {0, 1}, {2, 1}, {1, 0}, {0, 0}};
+    static const int deepv[5][2] = {{1, 1}, {0, 1}, {1, 2}, {0, 2}, {2, 2}};
+    const int (*variants)[2] = (c->deep && deep_depth(c->deep) <= HR1) ? deepv : shallow;
     struct Res { int o, d; double ms; };
     std::vector<Res> res;
     for (int v = 0; v < 5; ++v) {

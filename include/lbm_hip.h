@@ -179,8 +179,10 @@ int  lbm_load_state(lbm_ctx* c, const char* path);
  *                 "arith" 0 strict IEEE collision (bit-identical to the CPU oracle for normal-range operands: lbm_debug_strict_div2) | 1 FMA-contracted (<= 1e-10)
  *   strips:       "overlap" 0 launch and exchange serialised | 1 edge bands first, the exchange overlapped with the interior
  *                 rows of the SAME launch | 2 the exchange overlapped with the interior rows of the NEXT (extended)
- *                 launch; "deep_halo" 1|0 one exchange per two launches (both measured at lbm_initialise when a
- *                 communicator is attached, unless set here),
+ *                 launch; "deep_halo" 0 an exchange of LBM_HALO_ROWS rows after every launch | 1 after every second launch of a
+ *                 plan of up to three iterations per launch (a deep plan still exchanges after every launch) | 2 a deep plan too:
+ *                 2 x LBM_HALO_ROWS rows after every second launch of up to six iterations (both measured at lbm_initialise
+ *                 when a communicator is attached, unless set here),
  *                 "skip_exchange" 1 (diagnostic: no halo traffic, results invalid),
  *                 "graph" 0|1|2 replay the launch groups of a deep strip plan from a captured hipGraph: 1 (default) where the
  *                 transport is local to the process, 2 also between the ranks of a communicator (RCCL under capture:

@@ -25,6 +25,12 @@ for n in [int(v) for v in sys.argv[1:]] or (1, 2, 4, 8):
                        ("no-exchange deep", dict(deep)),
                        ("rccl-self deep ovl", dict(deep, loopback=2, overlap=1)),
                        ("rccl-self deep ser", dict(deep, loopback=2, overlap=0)),
+                       ("rccl-self lds6 PAIRS ovl", dict(lds6, loopback=2, overlap=1, deep_halo=2)),      # round 4: twelve rows per two launches
+                       ("rccl-self lds6 PAIRS ser", dict(lds6, loopback=2, overlap=0, deep_halo=2)),
+                       ("rccl-self lds6 PAIRS next", dict(lds6, loopback=2, overlap=2, deep_halo=2)),
+                       ("rccl-self deep PAIRS ovl", dict(deep, loopback=2, overlap=1, deep_halo=2)),
+                       ("rccl-self deep PAIRS ser", dict(deep, loopback=2, overlap=0, deep_halo=2)),
+                       ("rccl-self deep PAIRS next", dict(deep, loopback=2, overlap=2, deep_halo=2)),
                        ("rccl-self TUNED", dict(arith=1, trailing_pair=1, loopback=2)),
                        ("rccl-self ovl+deep", dict(base, loopback=2, overlap=1, deep_halo=1)),
                        ("rccl-self ser+deep", dict(base, loopback=2, overlap=0, deep_halo=1)),
