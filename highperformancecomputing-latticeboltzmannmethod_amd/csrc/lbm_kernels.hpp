@@ -714,7 +714,7 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step3_tile(const KArgs
 // into LDS (9*(TY+6)*(TX+6)*sizeof(T): 70.5 KB at 64x8 fp64, 35 KB fp32), regions 2 and 3 in place, then the tile.
 // HBM traffic per update ~ (1 + (TX+6)(TY+6)/(TX TY)) * 18 B; redundant collisions 1.45x at 64x8 — worth it where the
 // three-iteration kernel is close to the memory roof (fp32). Needs four valid rows beyond the rows written, so strips
-// (GR = 6 = 2 x 3) never use it; the plan measurement decides elsewhere. Bit-identical to four single launches (tests).
+// (six rows per exchange = 2 x 3) never use it; the plan measurement decides elsewhere. Bit-identical to four single launches (tests).
 template <typename T, int TY, int NTH, int AR = AR_STRICT>
 __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int TX = 64, HW = 3, R1W = TX + 2 * HW, R1H = TY + 2 * HW, LP = R1W;
@@ -866,7 +866,7 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs
 // iterations divides them, at the price of ~1.5x redundant collisions that such a grid has VALU time to spare for.
 // (Round 2's production shape — 32x16 tiles, 512 threads, D = 5/6, two blocks per CU: 125-130 GLUPS at 4096x1024 fp64 — is
 // superseded by k_stepc_col, which keeps the same region in registers instead of LDS, and is no longer built.)
-// Whole-domain launches only (rows outside the domain hold the permanent ghost values; a strip's ghost rows go GR = 6 deep).
+// Whole-domain launches only (rows outside the domain hold the permanent ghost values; a strip is refreshed six rows deep per single launch).
 // waves per SIMD the register allocation may assume: as many blocks as the LDS image allows on a CU (at most 32 waves)
 template <typename T, int TX, int TY, int D>
 constexpr int deep_waves_per_simd() {

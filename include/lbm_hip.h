@@ -110,7 +110,8 @@ int  lbm_get_solid(lbm_ctx* c, unsigned char* mask);
 
 /* ---- strip halo exchange (replaces Grid::exchange_ghost_cells, LBMGrid.h:249-283) ----
  * Device path: RCCL send/recv of the LBM_HALO_ROWS edge rows per face (one contiguous run in the row-interleaved
- * layout) once per two launches, on a side stream, overlapped with the interior update. `id128` is the 128-byte
+ * layout) once per launch of up to six iterations (or 2 x LBM_HALO_ROWS rows once per two such launches: option "deep_halo" 2,
+ * measured at lbm_initialise), on a side stream, overlapped with the interior update. `id128` is the 128-byte
  * ncclUniqueId produced by lbm_comm_unique_id on rank 0 and distributed by the launcher. Ranks are ordered bottom (0)
  * to top; attach the communicator before lbm_initialise. */
 int  lbm_comm_unique_id(void* id128);
