@@ -485,7 +485,8 @@ def main():
                               "graph": ("replayed" if graph_replays > 0 else ("off (multi-rank default; --set graph=2 asks for it)" if graph_opt < 2 else
                                         "refused: launch groups issued call by call")),
                               "graph_replays_rank0": graph_replays,
-                              "halo_bytes_per_face_and_exchange": hr * 9 * ((nx + 2 + 32 + 15) // 16 * 16) * (8 if args.precision == "f64" else 4)}
+                              # (from the library's own description of the measured schedule: six rows per launch or twelve per two)
+                              "halo_bytes_per_face_and_exchange": (lambda m: int(m.group(1)) if m else None)(re.search(r"(\d+) B per face and exchange", schedule_used))}
             line["strips"].update(parity)
             verdict = str(parity.get("parity", ""))
             if verdict.startswith("MISMATCH"):

@@ -40,7 +40,7 @@ def test_two_rank_bench_line_and_exit_code():
     for key in ("host_issue_us_per_iteration", "gpu_us_per_iteration", "graph", "halo_bytes_per_face_and_exchange",
                 "ms_per_step_compute_only", "ms_per_step_exchange_exposed", "schedule"):
         assert key in st, key
-    assert st["graph"].startswith("off") and line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
+    assert st["halo_bytes_per_face_and_exchange"] == 1783296 and st["graph"].startswith("off") and line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
 
 
 @pytest.mark.timeout(600)
