@@ -28,7 +28,7 @@ inline bool graph_wanted(const lbm_ctx* c, int remaining, int of, bool transport
     // one-rank communicator sending to itself captures and replays fine): a multi-rank run takes the graph path only when
     // asked to ("graph" 2) — a refused capture falls back, a hang in an untested collective path would not.
     if (c->nranks > 1 && c->use_graph < 2) return false;
-    if (!c->deep || deep_depth(c->deep) > HR1 || c->mid_pair || c->overlap == 2) return false;      // (pairs of launches: four groups = two whole pairs)
+    if (!c->deep || deep_depth(c->deep) > GR || c->mid_pair || c->overlap == 2) return false;      // (pairs of launches: four groups = two whole pairs)
     if (!(face_south(c) || face_north(c))) return false;
     const int depth = deep_depth(c->deep), iters = GRAPH_GROUPS * depth;
     if (remaining < iters + 4 * depth + 1) return false;                       // (plan_launch splits the END of a segment differently)

@@ -11,7 +11,12 @@
 // with "deep_halo" 2 — twelve and six
 inline bool device_transport(const lbm_ctx* c) { return c->group_n > 1 || (c->comm && c->nranks > 1) || c->loopback; }
 inline bool deep_pairs(const lbm_ctx* c) { return c->deep && deep_depth(c->deep) <= HR1 && c->deep_halo == 2 && device_transport(c); }
-inline int halo_rows(const lbm_ctx* c) { return deep_pairs(c) ? 2 * HR1 : HR1; }
+// (a deep LDS shape of seven / eight iterations per launch refreshes seven / eight: the frame holds twelve)
+inline int halo_rows(const lbm_ctx* c) {
+    if (deep_pairs(c)) return 2 * HR1;
+    if (c->deep && deep_depth(c->deep) > HR1 && deep_depth(c->deep) <= GR && device_transport(c)) return deep_depth(c->deep);
+    return HR1;
+}
 inline int ext_rows(const lbm_ctx* c) { return halo_rows(c) / 2; }
 struct FaceSpans {
     size_t cnt;       // elements per face message (halo_rows x pitch)
@@ -187,7 +192,10 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
         // Whether the faces are EXCHANGED in this call (strip_logic) or not (the plan probe), a context whose rows end at an
         // internal face has GR rows beyond them and no more: the seven- / eight-iteration shapes would read past the frame.
         const bool phys_face = face_south(c) || face_north(c);
-        const int deep = (c->deep && (!phys_face || deep_depth(c->deep) <= HR1)) ? deep_depth(c->deep) : 0;
+        // (with a device transport the exchange refreshes as many rows as the plan's launches are deep, up to the frame's
+        // twelve: the seven- / eight-iteration LDS shapes run on strips too; host-staged halos carry six)
+        const int hmax = (device_transport(c) || !strip_logic) ? GR : HR1;
+        const int deep = (c->deep && (!phys_face || deep_depth(c->deep) <= hmax)) ? deep_depth(c->deep) : 0;
         if (deep) {
             // `seg` iterations may be fused from here: up to the next force-output iteration (its post-collision state
             // must exist in memory) and the end of the call. A long segment takes the plan's depth; near its end the

@@ -232,3 +232,44 @@ def test_deep_pairs_on_one_strip_with_the_rccl_transport(lbm, loopback):
             if out[0][0] is not None:      # (interior rows: the ghost rows of the previous iteration's buffer are whatever was last received into it)
                 assert np.array_equal(out[0][0][1:-1], other[0][1:-1])
         assert (out[0][2] == -1) == (of == 150)
+
+
+@pytest.mark.parametrize("deep,precision", [(3, "f64"), (2, "f64"), (3, "f32")])
+def test_seven_and_eight_iteration_lds_shapes_on_strips(lbm, deep, precision):
+    """Round 4: with the twelve-row ghost frame the seven- / eight-iteration LDS shapes (k_stepd_tile 64x16 x 7, 32x32 x 8) run on
+    strips too — the exchange then refreshes seven / eight rows per face once per launch (fewer exchanges per iteration: one rank
+    of eight, 7.36 -> 6.78 us per iteration in the proxy). Groups of even and uneven strips, every overlap mode, device copies
+    and the RCCL loopback, eager and graph-replayed: bit-identical to the one-domain run."""
+    nx, ny, steps, of = 512, 300, 333, 70
+    kw = dict(inlet_velocity=0.05, cylinder_radius=0.1, precision=precision)
+    ftol = 1e-13 if precision == "f64" else 1e-5
+    plan = dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=deep)
+    with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1), **kw) as whole:
+        whole.initialise()
+        whole.step(steps, of)
+        w_fn, w_log = whole.populations("f_next"), whole.drain_force_log()
+    for bounds in (3, [(0, 150), (150, 14), (164, 136)]):
+        for extra in (dict(), dict(overlap=0), dict(group_threads=0)):
+            with lbm.Group(nx, ny, bounds, options=dict(plan, **extra), **kw) as g:
+                g.initialise()
+                assert all(f",{8 if deep == 3 else 7}," in m.kernel_name() and "k_stepd_tile" in m.kernel_name() for m in g.ctxs), g.ctxs[0].kernel_name()
+                g.step(steps, of)
+                assert g.first_unstable_step() == -1
+                assert np.array_equal(g.populations("f_next"), w_fn), (bounds, extra)
+                log = g.drain_force_log()
+                assert [r[0] for r in log] == [r[0] for r in w_log]
+                for (t, fx, fy), (_, wx, wy) in zip(log, w_log):
+                    assert abs(fx - wx) <= ftol * max(1.0, abs(wx)) and abs(fy - wy) <= ftol
+    out = []
+    for loopback, overlap, graph, d in ((1, 1, 0, 1), (1, 1, 0, deep), (2, 1, 0, deep), (2, 0, 0, deep), (2, 1, 1, deep)):
+        with lbm.Context(nx, 160, options=dict(plan, deep=d, loopback=loopback, overlap=overlap, graph=graph), **kw) as ctx:
+            if loopback == 2:
+                ctx.comm_init(0, 1, ctx.comm_unique_id())
+            ctx.initialise()
+            ctx.step(steps, 160)      # (four launch groups of eight iterations are replayed only far from a force output)
+            ctx.sync()
+            assert ctx.first_unstable_step() == -1
+            out.append((ctx.populations("f_next")[1:-1], ctx.drain_force_log()))
+            assert (ctx.graph_replays() > 0) == (graph == 1), ctx.strip_schedule()
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0]) and out[0][1] == other[1]

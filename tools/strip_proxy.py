@@ -25,6 +25,11 @@ for n in [int(v) for v in sys.argv[1:]] or (1, 2, 4, 8):
                        ("no-exchange deep", dict(deep)),
                        ("rccl-self deep ovl", dict(deep, loopback=2, overlap=1)),
                        ("rccl-self deep ser", dict(deep, loopback=2, overlap=0)),
+                       ("rccl-self lds7 ovl", dict(lds6, deep=2, loopback=2, overlap=1)),      # round 4: seven / eight iterations per launch on strips
+                       ("rccl-self lds7 ser", dict(lds6, deep=2, loopback=2, overlap=0)),
+                       ("no-exchange lds8", dict(lds6, deep=3)),
+                       ("rccl-self lds8 ovl", dict(lds6, deep=3, loopback=2, overlap=1)),
+                       ("rccl-self lds8 ser", dict(lds6, deep=3, loopback=2, overlap=0)),
                        ("rccl-self lds6 PAIRS ovl", dict(lds6, loopback=2, overlap=1, deep_halo=2)),      # round 4: twelve rows per two launches
                        ("rccl-self lds6 PAIRS ser", dict(lds6, loopback=2, overlap=0, deep_halo=2)),
                        ("rccl-self lds6 PAIRS next", dict(lds6, loopback=2, overlap=2, deep_halo=2)),
