@@ -275,7 +275,11 @@ int issue_before(lbm_ctx* c, const Launch& L) {
         HIPCHK(hipGetLastError());
         return LBM_OK;
     }
-    const int E = c->deep_now ? deep_rows(c, c->deep, L.depth) : L.depth > 1 ? c->pair_ty : HR1;   // one tile band (>= the rows that travel: see below)
+    // one tile band — and at least the rows that travel: the exchange reads them behind ev_edge, i.e. behind the EDGE launch only.
+    // (Round 4: with twelve- and eight-row exchanges a remainder launch of one iteration, whose band used to be six rows, left the
+    // rows beyond them to the interior launch — a race with the neighbour's pull that showed as a 1-in-15 mismatch of a threaded
+    // group across force outputs.)
+    const int E = std::max(c->deep_now ? deep_rows(c, c->deep, L.depth) : L.depth > 1 ? c->pair_ty : HR1, halo_rows(c));
     if (L.kind == KIND_EXTENDED) {   // all rows of the strip PLUS the ext_rows ghost rows next to each internal face
         const int es = face_south(c) ? ext_rows(c) : 0, en = face_north(c) ? ext_rows(c) : 0;
         int e0 = face_south(c) ? E : 0, e1 = face_north(c) ? E : 0;
