@@ -1,12 +1,12 @@
-// csrc/lbm_col.hip — the translation unit(s) of k_stepc_col (lbm_kernel_col.hpp): its 24 instantiations (five / six / seven
-// iterations x store policy x arithmetic x element type, twelve per element type and object file) and the launcher lbm_hip.hip calls (lbm_col_api.hpp).
+// csrc/lbm_col.hip — the translation unit(s) of k_stepc_col (lbm_kernel_col.hpp): its 30 instantiations (five / six / seven
+// iterations x store policy x arithmetic x element type, twelve per element type and object file, plus the six tall fp32 ones) and the launcher lbm_hip.hip calls (lbm_col_api.hpp).
 #include "lbm_kernel_col.hpp"
 #include "lbm_col_api.hpp"
 
 namespace lbmk {
 
 template <typename T>
-void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool contracted, hipStream_t s) {
+void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool contracted, bool tall, hipStream_t s) {
 #define LBM_KC(D_, R_, NT_, AR_) do { \
         constexpr int OW_ = col_tile_w(D_), OH_ = col_tile_h(D_, R_); \
         const int nb_ = ((a.nx + OW_ - 1) / OW_) * ((a.y_cnt + OH_ - 1) / OH_ + (a.y_cnt2 + OH_ - 1) / OH_); \
@@ -16,6 +16,15 @@ void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool
         if (contracted) { if (nt) LBM_KC(D_, RC, true, AR_CONTRACTED); else LBM_KC(D_, RC, false, AR_CONTRACTED); } \
         else { if (nt) LBM_KC(D_, RS, true, AR_STRICT); else LBM_KC(D_, RS, false, AR_STRICT); } } while (0)
     constexpr int RC = col_rows_per_thread((int)sizeof(T), false), RS = col_rows_per_thread((int)sizeof(T), true);
+    if constexpr (sizeof(T) == 4) {
+        if (tall) {     // 64 x 64 (strict: 64 x 48) regions, plain stores
+            constexpr int TC = col_rows_per_thread(4, false, true), TS = col_rows_per_thread(4, true, true);
+#define LBM_KT(D_) do { if (contracted) LBM_KC(D_, TC, false, AR_CONTRACTED); else LBM_KC(D_, TS, false, AR_STRICT); } while (0)
+            if (depth == 6) LBM_KT(6); else if (depth == 8) LBM_KT(8); else LBM_KT(7);
+#undef LBM_KT
+            return;
+        }
+    }
     if (depth == 5) LBM_KD(5); else if (depth == 7) LBM_KD(7); else LBM_KD(6);
 #undef LBM_KD
 #undef LBM_KC
@@ -25,6 +34,6 @@ void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool
 #ifndef LBM_COL_T
 #error "compile with -DLBM_COL_T=double or -DLBM_COL_T=float"
 #endif
-template void launch_col<LBM_COL_T>(const KArgs<LBM_COL_T>&, const K2Extra<LBM_COL_T>&, int, bool, bool, hipStream_t);
+template void launch_col<LBM_COL_T>(const KArgs<LBM_COL_T>&, const K2Extra<LBM_COL_T>&, int, bool, bool, bool, hipStream_t);
 
 }  // namespace lbmk

@@ -11,14 +11,21 @@ constexpr int COL_NW = 8;                 // waves per block; two blocks per CU
 // 128 VGPRs leave beside 4 x 9 fp64 populations: 3 rows (64 x 24), 122 VGPRs, no scratch. Round 3's strict kernels spilled 12
 // VGPRs (44 B of scratch per lane, 20 % more HBM writes); measured at 4096x1024 (tools/colbench, round 4): 129.9 GLUPS on
 // 3 rows x five iterations against 106-114 on 4 rows. Contracted arithmetic is faster on 4 rows (158-163 against 145-150).
-constexpr int col_rows_per_thread(int esize, bool strict) { return (esize == 8 && strict) ? 3 : 4; }
+// TALL (fp32 only, round 4): 8 rows per thread, a 64 x 64 region. Nine fp32 populations x 8 rows are 72 registers — what 4 fp64
+// rows take — so the tall block also runs two per CU (121-127 VGPRs), but stores 52 x 52 of 64 x 64 cells at seven iterations where
+// the 64 x 32 region stores 54 x 22 at six: 1.19 x instead of 1.45 x the lattice read per launch, 17 % fewer redundant collisions.
+// 16384x4096 fp32 (tools/colbench): 311 GLUPS at seven iterations, 302 at six / eight, against 289-292 on 64 x 32; at 4096x1024 (three
+// rounds of blocks) it loses, 217-226 against 263 — a measured candidate, never a rule. fp32 strict: 6 rows (64 x 48).
+constexpr int col_rows_per_thread(int esize, bool strict, bool tall = false) {
+    return tall && esize == 4 ? (strict ? 6 : 8) : (esize == 8 && strict) ? 3 : 4;
+}
 // output tile of a launch of `depth` iterations
 constexpr int col_tile_w(int depth) { return 64 - 2 * (depth - 1); }
 constexpr int col_tile_h(int depth, int rows_per_thread) { return rows_per_thread * COL_NW - 2 * (depth - 1); }
 
-// k_stepc_col<T, rows per thread, COL_NW, depth, nt, arith> over the rows a.y_lo.. / a.y_lo2.. of the launch (depth 5, 6 or — whole
-// domains only: a strip's ghost rows go six deep — 7)
+// k_stepc_col<T, rows per thread, COL_NW, depth, nt, arith> over the rows a.y_lo.. / a.y_lo2.. of the launch: depth 5, 6 or 7 on
+// 64 x 32 regions; tall (fp32; plain stores only — non-temporal ones cost 14 % there): depth 6, 7 or 8
 template <typename T>
-void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool contracted, hipStream_t s);
+void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool contracted, bool tall, hipStream_t s);
 
 }  // namespace lbmk

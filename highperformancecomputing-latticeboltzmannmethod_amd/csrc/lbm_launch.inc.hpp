@@ -84,10 +84,11 @@ void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
 // (k_stepc_col, R = 4 rows per thread x 8 waves = a 64 x 32 region per block, two blocks per CU) with five / six iterations —
 // a plan of either uses both depths, and on a context without strip faces seven iterations too, for what a segment leaves
 // over (20 = 7 + 7 + 6; at 4096x1024 fp64 seven iterations run at 160.6 GLUPS against 161.7 for six — eight, 154.3, are
-// not built). Ids 4 / 5 were round 2's 32x16 LDS tiles: retired.
+// not built); 9: the same family with seven iterations as the plan's depth (8192x2048 fp64: 175.9 against 169.9); 8: fp32 only, the same kernel on TALL 64 x 64 regions (eight rows per thread) with seven iterations, six / eight for
+// what a segment leaves over. Ids 4 / 5 were round 2's 32x16 LDS tiles: retired.
 // rows of one band of tiles of a launch of `depth` iterations (the edge bands of a strip are one band each)
 inline int deep_rows(const lbm_ctx* c, int id, int depth) {
-    if (deep_is_col(id)) return col_tile_h(depth, col_rows_per_thread((int)c->esize, c->arith == 0));
+    if (deep_is_col(id)) return col_tile_h(depth, col_rows_per_thread((int)c->esize, c->arith == 0, deep_is_tall(id)));
     return id == 3 ? 32 : 16;
 }
 // A fused kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt): iterations a.t .. a.t + depth - 1 (depth 2..8).
@@ -102,7 +103,7 @@ void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream
     e.ntl = c->use_ntl;
     const bool fast = c->arith == AR_CONTRACTED;
     if (c->deep_now && deep_is_col(shape)) {    // D iterations with the lattice in registers (k_stepc_col, lbm_col.hip)
-        launch_col<T>(a, e, depth, c->use_nt != 0, fast, s);
+        launch_col<T>(a, e, depth, c->use_nt != 0, fast, deep_is_tall(shape), s);
         return;
     }
     if (c->deep_now) {    // D iterations on a deep LDS tile (k_stepd_tile; whole-domain launches of small grids)

@@ -14,15 +14,18 @@ namespace lbmk {
 // layout 0 planar / 1 row-interleaved; variant 0 k_step_vec / 1 k_step_site for single iterations; nt: non-temporal stores;
 // alternate: walk direction alternates per launch; fuse: iterations per launch of the tile kernels (1..4) or of the deep shape;
 // ty: tile height of the two- / three-iteration tile kernels (8 or 12); xcd: XCD-aware tile walk; deep: 0, or the deep shape
-// (1..3: k_stepd_tile six / seven / eight iterations; 6 / 7: k_stepc_col five / six iterations in registers); ntl: the register
-// kernel's level-1 loads are non-temporal
+// (1..3: k_stepd_tile six / seven / eight iterations; 6 / 7: k_stepc_col five / six iterations in registers on 64x32 regions;
+// 9: the same kernel with SEVEN iterations as the plan's depth — the largest grids; 8: fp32 only, k_stepc_col seven iterations
+// on TALL 64x64 regions — lbm_col_api.hpp); ntl: the register kernel's level-1 loads
+// are non-temporal
 struct Plan { int layout, variant, nt, alternate, fuse, ty, xcd; std::string name; int deep = 0; int ntl = 0; };
 
-inline bool deep_is_col(int id) { return id == 6 || id == 7; }
+inline bool deep_is_col(int id) { return id >= 6 && id <= 9; }
+inline bool deep_is_tall(int id) { return id == 8; }
 inline bool deep_valid(int id) { return id == 0 || (id >= 1 && id <= 3) || deep_is_col(id); }
 inline int deep_depth(int id) {
-    static const int d[8] = {0, 6, 7, 8, 0, 0, 5, 6};
-    return id >= 0 && id <= 7 ? d[id] : 0;
+    static const int d[10] = {0, 6, 7, 8, 0, 0, 5, 6, 7, 7};
+    return id >= 0 && id <= 9 ? d[id] : 0;
 }
 inline const char* deep_tile(int id) {
     static const char* t[4] = {"", "64,16", "64,16", "32,32"};
@@ -92,6 +95,17 @@ inline std::vector<Plan> plan_candidates(const PlanQuery& q, const Plan& fixed) 
     cand.push_back({1, 1, 0, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-load/xcd", 7, 1});
     cand.push_back({1, 1, 0, 1, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-load/alternate/xcd", 7, 1});
     cand.push_back({1, 1, 0, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/nt-load/xcd", 6, 1});
+    // (round 4: seven iterations as the plan's own depth pay on the largest grids — 8192x2048 fp64 175.9 GLUPS against 169.9 for six;
+    // at 4096x1024 they lose, 157-160 against 160-166)
+    if (!small_grid) {
+        cand.push_back({1, 1, 0, 0, 7, 12, 1, "row-interleaved/7-step 64x32 in registers/xcd", 9});
+        cand.push_back({1, 1, 0, 1, 7, 12, 1, "row-interleaved/7-step 64x32 in registers/alternate/xcd", 9});
+    }
+    // (round 4, fp32: 64x64 regions — 16384x4096 311 GLUPS against 289-292 on 64x32; loses on three rounds of blocks, 4096x1024)
+    if (q.esize == 4 && !small_grid) {
+        cand.push_back({1, 1, 0, 0, 7, 12, 1, "row-interleaved/7-step 64x64 in registers/xcd", 8});
+        cand.push_back({1, 1, 0, 1, 7, 12, 1, "row-interleaved/7-step 64x64 in registers/alternate/xcd", 8});
+    }
     cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x16/nt-store/xcd", 1});
     if (small_grid && !q.faces) {   // one round of LDS-filling tiles: a launch's load and store phases are paid once per 7-8 iterations
         cand.push_back({1, 1, 1, 0, 7, 12, 1, "row-interleaved/7-step 64x16/nt-store/xcd", 2});
@@ -118,8 +132,9 @@ inline std::vector<Plan> plan_candidates(const PlanQuery& q, const Plan& fixed) 
 inline std::string plan_kernel_name(int fuse, int deep, int pair_ty, int nt, int arith, int esize, bool vec) {
     char name[96];
     const char* t = esize == 4 ? "float" : "double";
-    const char* nts = nt ? "true" : "false";
-    if (fuse > 2 && deep_is_col(deep)) snprintf(name, sizeof(name), "k_stepc_col<%s,%d,%d,%d,%s,%d>", t, col_rows_per_thread(esize, arith == 0), COL_NW, deep_depth(deep), nts, arith);
+    const bool tall = deep_is_tall(deep) && esize == 4;      // (tall regions: plain stores only)
+    const char* nts = nt && !tall ? "true" : "false";
+    if (fuse > 2 && deep_is_col(deep)) snprintf(name, sizeof(name), "k_stepc_col<%s,%d,%d,%d,%s,%d>", t, col_rows_per_thread(esize, arith == 0, tall), COL_NW, deep_depth(deep), nts, arith);
     else if (fuse > 2 && deep) snprintf(name, sizeof(name), "k_stepd_tile<%s,%s,%d,%d>", t, deep_tile(deep), deep_depth(deep), arith);
     else if (fuse == 4) snprintf(name, sizeof(name), "k_step4_tile<%s,8,%d,%d>", t, esize == 8 ? 1024 : 512, arith);
     else if (fuse > 1) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%d>", fuse, t, pair_ty, pair_ty == 12 ? (fuse == 3 ? 1024 : 768) : 512, arith);

@@ -208,6 +208,7 @@ inline int plan_launch(lbm_ctx* c, int remaining, int of, bool transport, bool s
             auto in_family = [&](int d) {
                 if (d == deep) return true;
                 if (!deep_is_col(c->deep)) return false;
+                if (deep_is_tall(c->deep)) return d == 6 || (d == 8 && !phys_face);       // (a strip exchanges seven rows on this plan)
                 return d == 5 || d == 6 || (d == 7 && !phys_face);
             };
             int fam_min = deep;

@@ -66,8 +66,13 @@ PLANS = {
     # non-temporal level-1 loads in the register kernel (round 4: a store-policy-like choice of the plan measurement)
     "rowil-col6-ntl-alt": dict(tune=0, layout=1, variant=1, nt=0, ntl=1, alternate=1, pair_ty=12, xcd=1, deep=7),
     "fast-rowil-col6-ntl": dict(tune=0, layout=1, variant=1, nt=0, ntl=1, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
+    # seven iterations as the plan's own depth (round 4: what the largest grids' measurement picks; strips exchange seven rows)
+    "rowil-col7-alt": dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair_ty=12, xcd=1, deep=9),
+    "fast-rowil-col7": dict(tune=0, layout=1, variant=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=9, arith=1),
 }
 FAST = [k for k, v in PLANS.items() if v and v.get("arith")]
+# fp32 contexts only (round 4): seven iterations per launch on TALL 64x64 regions in registers (strict arithmetic: 64x48)
+TALL_F32 = dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair_ty=12, xcd=1, deep=8)
 
 
 def strict(plan):
@@ -888,6 +893,11 @@ def test_fp32_tracks_the_oracle_on_fused_plans_1024x256(lbm):
             ctx.step(steps, 0)
             assert ctx.first_unstable_step() == -1
             out[plan] = ctx.macros()
+    with lbm.Context(nx, ny, precision="f32", options=TALL_F32, **kw) as ctx:
+        ctx.initialise()
+        ctx.step(steps, 0)
+        assert ctx.first_unstable_step() == -1 and "k_stepc_col<float,6,8,7" in ctx.kernel_name().replace(" ", "")
+        out["rowil-col7-tall"] = ctx.macros()
     er, eu = macro_errors(*out["auto"], *ref)
     print(f"fp32 vs the fp64 oracle, 1024x256 x {steps}: rho {er:.3e}, u {eu:.3e}")
     # stated tolerance 2e-4 = about twice what was measured on MI355X (rho 1.2e-5, u 9.2e-5; SURVEY §8d C5: "≈1e-4 rel on u after
@@ -942,7 +952,7 @@ def test_c5_grid_16384x4096_fp32_single_gpu(lbm):
     print(f"C5 fp32 vs fp64 (HIP) x {steps}: rho {er:.3e}, u {eu:.3e}, force {ef:.3e}")
     del m64
     assert er < 2e-5 and eu < 2e-4 and ef < 1e-4, (er, eu, ef)
-    for options in (None, PLANS["rowil-fuse3-12-nt-xcd"], PLANS["rowil-col5-nt"], PLANS["rowil-deep6-nt"], PLANS["rowil-site-nt"]):
+    for options in (None, PLANS["rowil-fuse3-12-nt-xcd"], PLANS["rowil-col5-nt"], PLANS["rowil-deep6-nt"], PLANS["rowil-site-nt"], TALL_F32):
         m2, log2, _, _ = run(options)
         for a, b in zip((rho, ux, uy), m2):
             assert np.array_equal(a, b), options

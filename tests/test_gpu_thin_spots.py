@@ -237,10 +237,10 @@ def test_deep_pairs_on_one_strip_with_the_rccl_transport(lbm, loopback):
         assert (out[0][2] == -1) == (of == 150)
 
 
-@pytest.mark.parametrize("deep,precision", [(3, "f64"), (2, "f64"), (3, "f32")])
+@pytest.mark.parametrize("deep,precision", [(3, "f64"), (2, "f64"), (3, "f32"), (9, "f64")])
 def test_seven_and_eight_iteration_lds_shapes_on_strips(lbm, deep, precision):
     """Round 4: with the twelve-row ghost frame the seven- / eight-iteration LDS shapes (k_stepd_tile 64x16 x 7, 32x32 x 8) run on
-    strips too — the exchange then refreshes seven / eight rows per face once per launch (fewer exchanges per iteration: one rank
+    strips too, and so does the register kernel with seven iterations as its plan's depth ("deep" 9) — the exchange then refreshes seven / eight rows per face once per launch (fewer exchanges per iteration: one rank
     of eight, 7.36 -> 6.78 us per iteration in the proxy). Groups of even and uneven strips, every overlap mode, device copies
     and the RCCL loopback, eager and graph-replayed: bit-identical to the one-domain run."""
     nx, ny, steps, of = 512, 300, 333, 70
@@ -255,7 +255,8 @@ def test_seven_and_eight_iteration_lds_shapes_on_strips(lbm, deep, precision):
         for extra in (dict(), dict(overlap=0), dict(group_threads=0)):
             with lbm.Group(nx, ny, bounds, options=dict(plan, **extra), **kw) as g:
                 g.initialise()
-                assert all(f",{8 if deep == 3 else 7}," in m.kernel_name() and "k_stepd_tile" in m.kernel_name() for m in g.ctxs), g.ctxs[0].kernel_name()
+                assert all(f",{8 if deep == 3 else 7}," in m.kernel_name() and ("k_stepc_col" if deep == 9 else "k_stepd_tile") in m.kernel_name()
+                           for m in g.ctxs), g.ctxs[0].kernel_name()
                 g.step(steps, of)
                 assert g.first_unstable_step() == -1
                 assert np.array_equal(g.populations("f_next"), w_fn), (bounds, extra)
@@ -270,6 +271,73 @@ def test_seven_and_eight_iteration_lds_shapes_on_strips(lbm, deep, precision):
                 ctx.comm_init(0, 1, ctx.comm_unique_id())
             ctx.initialise()
             ctx.step(steps, 160)      # (four launch groups of eight iterations are replayed only far from a force output)
+            ctx.sync()
+            assert ctx.first_unstable_step() == -1
+            out.append((ctx.populations("f_next")[1:-1], ctx.drain_force_log()))
+            assert (ctx.graph_replays() > 0) == (graph == 1), ctx.strip_schedule()
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0]) and out[0][1] == other[1]
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+def test_tall_fp32_regions_in_registers(lbm, arith):
+    """Round 4, fp32 only ("deep" 8): k_stepc_col on 64x64 regions (eight rows per thread; strict arithmetic: six, 64x48) with
+    seven iterations per launch and six / eight for what a segment leaves over — the measured plan of 16384x4096 fp32. Same
+    per-cell operation sequence as one launch per iteration: bit-identical populations and forces on ragged grids with every
+    boundary and the cylinder (on the inlet column too), as a whole domain, as groups of even / uneven strips (seven rows per
+    exchange), over the one-rank RCCL transport, eager and replayed from a graph. fp64 contexts refuse the shape."""
+    with pytest.raises(lbm.LbmError, match="fp32 only"):
+        lbm.Context(256, 64, precision="f64", options=dict(tune=0, deep=8))
+    rows = 8 if arith else 6
+    site = dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1, arith=arith)
+    tall = dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair_ty=12, xcd=1, deep=8, arith=arith)
+    for (nx, ny, steps, of, kw) in ((300, 170, 333, 45, dict(inlet_velocity=0.05, cylinder_radius=0.1)),
+                                    (1024, 256, 200, 0, dict(inlet_velocity=0.1)),
+                                    (190, 140, 150, 31, dict(inlet_velocity=0.04, cylinder_x=0.02, cylinder_radius=0.12))):
+        kw = dict(kw, precision="f32")
+        with lbm.Context(nx, ny, options=site, **kw) as whole:
+            whole.initialise()
+            whole.step(steps, of)
+            w_fn, w_log = whole.populations("f_next"), whole.drain_force_log()
+        for extra in (dict(), dict(trailing_pair=1), dict(layout=0, alternate=0)):
+            with lbm.Context(nx, ny, options=dict(tall, timing=1, **extra), **kw) as ctx:
+                ctx.initialise()
+                assert f"k_stepc_col<float,{rows},8,7,false,{arith}>" == ctx.kernel_name().replace(" ", ""), ctx.kernel_name()
+                ctx.step(steps, of)
+                if extra.get("trailing_pair"):
+                    ctx.step(1, 0)
+                    with lbm.Context(nx, ny, options=site, **kw) as w1:
+                        w1.initialise()
+                        w1.step(steps, of)
+                        w1.step(1, 0)
+                        ref_fn = w1.populations("f_next")
+                else:
+                    ref_fn = w_fn
+                assert ctx.first_unstable_step() == -1
+                assert np.array_equal(ctx.populations("f_next"), ref_fn), (nx, ny, extra)
+                assert ctx.drain_force_log() == w_log
+        if ny < 170:
+            continue
+        for bounds in (2, [(0, ny - 100), (ny - 100, 14), (ny - 86, 86)]):
+            for extra in (dict(), dict(overlap=0, group_threads=0)):
+                with lbm.Group(nx, ny, bounds, options=dict(tall, **extra), **kw) as g:
+                    g.initialise()
+                    assert all(f"<float,{rows},8,7," in m.kernel_name().replace(" ", "") for m in g.ctxs), g.ctxs[0].kernel_name()
+                    g.step(steps, of)
+                    assert g.first_unstable_step() == -1
+                    assert np.array_equal(g.populations("f_next"), w_fn), (nx, ny, bounds, extra)
+                    log = g.drain_force_log()
+                    assert [r[0] for r in log] == [r[0] for r in w_log]
+                    for (t, fx, fy), (_, wx, wy) in zip(log, w_log):
+                        assert abs(fx - wx) <= 1e-5 * max(1.0, abs(wx)) and abs(fy - wy) <= 1e-5
+    out = []
+    kw = dict(inlet_velocity=0.05, cylinder_radius=0.1, precision="f32")
+    for loopback, overlap, graph, d in ((1, 1, 0, 7), (1, 1, 0, 8), (2, 1, 0, 8), (2, 0, 0, 8), (2, 1, 1, 8)):
+        with lbm.Context(512, 200, options=dict(tall, deep=d, loopback=loopback, overlap=overlap, graph=graph), **kw) as ctx:
+            if loopback == 2:
+                ctx.comm_init(0, 1, ctx.comm_unique_id())
+            ctx.initialise()
+            ctx.step(333, 160)
             ctx.sync()
             assert ctx.first_unstable_step() == -1
             out.append((ctx.populations("f_next")[1:-1], ctx.drain_force_log()))

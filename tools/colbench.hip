@@ -171,6 +171,19 @@ std::vector<Variant<T>> variants() {
     v.push_back(col_variant<T, 3, 8, 5, AR>(true));
     v.push_back(col_variant<T, 3, 8, 6, AR>(true));
     v.push_back(col_variant<T, 3, 8, 6, AR>(false, true));
+    if constexpr (sizeof(T) == 8) {        // fp64: 64x64 regions need 16 waves (one block per CU)
+        v.push_back(col_variant<T, 4, 16, 6, AR>(false, true));
+        v.push_back(col_variant<T, 4, 16, 7, AR>(false, true));
+        v.push_back(col_variant<T, 4, 16, 8, AR>(false, true));
+    }
+    if constexpr (sizeof(T) == 4) {        // fp32: taller regions (state = 9 R registers per thread)
+        v.push_back(col_variant<T, 6, 8, 6, AR>(false, true));
+        v.push_back(col_variant<T, 6, 8, 7, AR>(false, true));
+        v.push_back(col_variant<T, 8, 8, 6, AR>(false, true));
+        v.push_back(col_variant<T, 8, 8, 7, AR>(false, true));
+        v.push_back(col_variant<T, 8, 8, 8, AR>(false, true));
+        v.push_back(col_variant<T, 8, 8, 8, AR>(true, true));
+    }
     v.push_back(slide_variant<T, 4, 8, 6, AR>(false));
     v.push_back(slide_variant<T, 4, 8, 6, AR>(true));
     v.push_back(slide_variant<T, 4, 8, 5, AR>(false));
