@@ -45,36 +45,7 @@ __device__ __forceinline__ double from_right(double v) {
 __device__ __forceinline__ float from_left(float v) { return __builtin_bit_cast(float, dpp_shr1(__builtin_bit_cast(unsigned, v))); }
 __device__ __forceinline__ float from_right(float v) { return __builtin_bit_cast(float, dpp_shl1(__builtin_bit_cast(unsigned, v))); }
 
-// In-kernel phase record (tools/colbench -DLBM_COL_PROF only; never in the library): lane 0 of every wave writes the 100 MHz
-// real-time counter at the marks below, plus HW_ID / XCC_ID, so that the host can lay the blocks of one CU side by side (profiles/r04).
-#ifdef LBM_COL_PROF
-constexpr int PROF_SLOTS = 96;
-__device__ unsigned long long* lbm_prof_buf;     // [block][wave][PROF_SLOTS]
-__device__ __forceinline__ void prof_mark(int blk, int nw, int w, int slot) {
-    asm volatile("" ::: "memory");
-    if (((int)threadIdx.x & 63) == 0 && slot < PROF_SLOTS) {
-        unsigned long long t;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");    // 100 MHz, chip-wide (s_memtime: per-CU offsets)
-        lbm_prof_buf[((size_t)blk * nw + w) * PROF_SLOTS + slot] = t;
-    }
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void prof_ids(int blk, int nw, int w) {
-    if (((int)threadIdx.x & 63) == 0) {
-        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
-        unsigned long long rt;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt) :: "memory");
-        lbm_prof_buf[((size_t)blk * nw + w) * PROF_SLOTS + PROF_SLOTS - 1] = ((unsigned long long)xcc << 32) | hw;
-        lbm_prof_buf[((size_t)blk * nw + w) * PROF_SLOTS + PROF_SLOTS - 2] = rt;
-    }
-}
-#define LBM_PROF(blk, nw, w, slot) prof_mark(blk, nw, w, slot)
-#define LBM_PROF_IDS(blk, nw, w) prof_ids(blk, nw, w)
-#else
-#define LBM_PROF(blk, nw, w, slot) do {} while (0)
-#define LBM_PROF_IDS(blk, nw, w) do {} while (0)
-#endif
-
+// (in-kernel phase record, tools/colbench -DLBM_COL_PROF only: LBM_PROF / LBM_PROF_IDS, lbm_kernels.hpp)
 // waves per SIMD the register allocation may assume: two blocks per CU when they fit 32 waves, else one
 template <int NW> constexpr int col_waves_per_simd() { return NW <= 8 ? (2 * NW) / 4 : NW / 4; }
 

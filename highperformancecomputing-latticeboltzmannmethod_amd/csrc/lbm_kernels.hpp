@@ -859,6 +859,36 @@ __global__ void __launch_bounds__(NTH, (2 * NTH / 256)) k_step4_tile(const KArgs
     if (bad) atomicMin(a.unstable_t, *a.t_base + a.t + 3);
 }
 
+// In-kernel phase record (tools/colbench -DLBM_COL_PROF only; never in the library): lane 0 of every wave writes the 100 MHz
+// real-time counter at the marks below, plus HW_ID / XCC_ID, so that the host can lay the blocks of one CU side by side (profiles/r04).
+#ifdef LBM_COL_PROF
+constexpr int PROF_SLOTS = 96;
+__device__ unsigned long long* lbm_prof_buf;     // [block][wave][PROF_SLOTS]
+__device__ __forceinline__ void prof_mark(int blk, int nw, int w, int slot) {
+    asm volatile("" ::: "memory");
+    if (((int)threadIdx.x & 63) == 0 && slot < PROF_SLOTS) {
+        unsigned long long t;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");    // 100 MHz, chip-wide (s_memtime: per-CU offsets)
+        lbm_prof_buf[((size_t)blk * nw + w) * PROF_SLOTS + slot] = t;
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void prof_ids(int blk, int nw, int w) {
+    if (((int)threadIdx.x & 63) == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
+        unsigned long long rt;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt) :: "memory");
+        lbm_prof_buf[((size_t)blk * nw + w) * PROF_SLOTS + PROF_SLOTS - 1] = ((unsigned long long)xcc << 32) | hw;
+        lbm_prof_buf[((size_t)blk * nw + w) * PROF_SLOTS + PROF_SLOTS - 2] = rt;
+    }
+}
+#define LBM_PROF(blk, nw, w, slot) prof_mark(blk, nw, w, slot)
+#define LBM_PROF_IDS(blk, nw, w) prof_ids(blk, nw, w)
+#else
+#define LBM_PROF(blk, nw, w, slot) do {} while (0)
+#define LBM_PROF_IDS(blk, nw, w) do {} while (0)
+#endif
+
 // D iterations per launch (D = 6..8) on a TX x TY tile: k_step4_tile generalised — level 1 from HBM into an LDS image of the
 // (TX + 2(D-1)) x (TY + 2(D-1)) region, levels 2..D-1 in place (pull into registers, barrier, compute, overwrite, barrier),
 // level D the tile -> HBM, on 64x16 / 32x32 tiles of 1024 threads: for grids so small that one launch is a single round of
@@ -932,6 +962,9 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
     // logic, buffer addressing); a block takes one of the two (block-uniform), so neither pays for merging with the other.
     auto run = [&]<bool LEAN>() {
         bool bad = false;
+        [[maybe_unused]] const int pb = (int)(blockIdx.y * gridDim.x + blockIdx.x), pw = (int)threadIdx.x >> 6;
+        LBM_PROF_IDS(pb, NTH / 64, pw);
+        LBM_PROF(pb, NTH / 64, pw, 0);
 #pragma unroll
         for (int r = threadIdx.x; r < R1W * R1H; r += NTH) {                 // level 1 on region 1: iteration t
             int ry, rx;
@@ -963,6 +996,7 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
             for (int i = 0; i < Q; ++i) lds[i][ry][rx] = f[i];
         }
         if (bad) atomicMin(a.unstable_t, *a.t_base + a.t);
+        LBM_PROF(pb, NTH / 64, pw, 1);
         __syncthreads();
         auto in_place = [&]<int L>() {                                        // level L on region L = region 1 shrunk by L-1 rings
             constexpr int O = L - 1, RW = R1W - 2 * O, RH = R1H - 2 * O, CPT = (RW * RH + NTH - 1) / NTH;
@@ -1004,6 +1038,7 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
             }
             if (badl) atomicMin(a.unstable_t, *a.t_base + a.t + L - 1);
             __syncthreads();
+            LBM_PROF(pb, NTH / 64, pw, L);
         };
         [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (in_place.template operator()<Ls + 2>(), ...); }(std::make_integer_sequence<int, D - 2>{});
         bad = false;
@@ -1036,6 +1071,11 @@ __global__ void __launch_bounds__(TX * TY, (deep_waves_per_simd<T, TX, TY, D>())
             }
         }
         if (bad) atomicMin(a.unstable_t, *a.t_base + a.t + D - 1);
+        LBM_PROF(pb, NTH / 64, pw, D);                  // stores issued
+#ifdef LBM_COL_PROF
+        __builtin_amdgcn_s_waitcnt(0x0f70);             // vmcnt(0): ... and drained
+        LBM_PROF(pb, NTH / 64, pw, D + 1);
+#endif
     };
     if (lean) run.template operator()<true>();
     else run.template operator()<false>();

@@ -93,7 +93,7 @@ struct Lattice {
     int unstable() { int v; CK(hipMemcpyAsync(&v, d_unst, sizeof(int), hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); return v; }
 };
 
-template <typename T> struct Variant { std::string name; int depth; std::function<void(Lattice<T>&)> launch; };
+template <typename T> struct Variant { std::string name; int depth; std::function<void(Lattice<T>&)> launch; int waves = 8; };
 
 template <typename T, int R, int NW, int D, int AR>
 Variant<T> col_variant(bool nt, bool alt = false, int persist = 0) {
@@ -155,13 +155,15 @@ Variant<T> tile_variant() {
         dim3 grid((L.nx + TX - 1) / TX, (L.ny + TY - 1) / TY);
         KArgs<T> a = L.args(L.t);
         hipLaunchKernelGGL((k_stepd_tile<T, TX, TY, D, AR>), grid, dim3(TX * TY), 0, L.s, a, L.extra());
-    }};
+    }, TX * TY / 64};
 }
 
 template <typename T, int AR>
 std::vector<Variant<T>> variants() {
     std::vector<Variant<T>> v;
     v.push_back(tile_variant<T, 32, 16, 5, AR>());
+    v.push_back(tile_variant<T, 32, 32, 8, AR>());
+    v.push_back(tile_variant<T, 64, 16, 6, AR>());
     v.push_back(col_variant<T, 4, 8, 5, AR>(true));
     v.push_back(col_variant<T, 4, 8, 6, AR>(true));
     v.push_back(col_variant<T, 4, 8, 6, AR>(false));
@@ -276,7 +278,7 @@ void profile(int nx, int ny, const std::string& filter, const std::string& outdi
     Lattice<T> L(nx, ny);
     for (auto& v : variants<T, AR>()) {
         if (v.name.find(filter) == std::string::npos) continue;
-        const size_t nblk = 8192, nw = 8, n = nblk * nw * PROF_SLOTS;
+        const size_t nblk = 8192, nw = (size_t)v.waves, n = nblk * nw * PROF_SLOTS;
         unsigned long long* d; CK(hipMalloc(&d, n * 8));
         CK(hipMemcpyToSymbol(HIP_SYMBOL(lbmk::lbm_prof_buf), &d, sizeof(d)));
         L.init();

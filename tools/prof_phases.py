@@ -43,6 +43,18 @@ def describe(path, show_cu=None):
     print("   phase (mark k-1 -> k) of wave 0, us: median / p10 / p90 / max   [blocks]")
     for k, dur in ph:
         print(f"     {k:3d}: {np.median(dur):7.2f} {np.percentile(dur,10):7.2f} {np.percentile(dur,90):7.2f} {dur.max():7.2f}   [{len(dur)}]")
+    # per wave index of a block: when the wave starts (relative to its block's first wave) and how long its level 1 takes
+    nwv = int(d[:, 1].max()) + 1
+    blocks = sorted(set(d[:, 0].tolist()))
+    bix = {b: i for i, b in enumerate(blocks)}
+    W0 = np.full((len(blocks), nwv), np.nan); W1 = np.full((len(blocks), nwv), np.nan)
+    for r in range(len(d)):
+        if used[r, 0] and used[r, 1]:
+            W0[bix[d[r, 0]], int(d[r, 1])] = t[r, 0]; W1[bix[d[r, 0]], int(d[r, 1])] = t[r, 1]
+    b0 = np.nanmin(W0, axis=1)
+    print("   per wave index: start after the block's first wave / its level 1 (mark 0 -> 1), us (medians): "
+          + " ".join(f"{np.nanmedian(W0[:, k] - b0):.2f}/{np.nanmedian(W1[:, k] - W0[:, k]):.2f}" for k in range(nwv)))
+    print(f"   a block's first wave start -> its last wave's level 1 done: median {np.nanmedian(np.nanmax(W1, axis=1) - b0):.2f} us")
     first = tw[:, 0]
     last = np.array([tw[i, uw[i]].max() for i in range(len(tw))])
     life = last - first
