@@ -156,7 +156,7 @@ def measured_traffic(nx, local_ny, precision, kernel, layout="", build_id=None):
 
 PMC_GROUPS = (("FETCH_SIZE",), ("WRITE_SIZE",),
               ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"))
-_INIT_KERNEL = re.compile(r"k_step_site<\w+,1,|k_step_vec<\w+,\d+,1,")      # the collide-only launch of lbm_initialise
+_INIT_KERNEL = re.compile(r"k_step_site<\w+,1,")      # the collide-only launch of lbm_initialise
 
 
 _LIVE_BROKEN = []      # why the live passes were given up in this run, if they were (one failure: no second attempt, no second timeout)

@@ -48,10 +48,11 @@ def build_all(force=False, verbose=False):
     if force or embedded_id() != want:
         # -ffp-contract=off: no fused multiply-add is formed behind the source's back, so every formulation of the
         # step kernel (site / vector / fused, any layout) and the strict-IEEE oracle evaluate the same operation sequence.
-        # Three objects compiled side by side (the column kernel's instantiations of one element type take as long as all
+        # Five objects compiled side by side (the column kernel's instantiations of one element type take as long as all
         # the other kernels together), then linked.
         units = [("lbm_hip.hip", ["-DLBM_BUILD_ID_STR=\"" + want + "\""], "lbm_hip.o"),
-                 ("lbm_col.hip", ["-DLBM_COL_T=double"], "lbm_col_f64.o"), ("lbm_col.hip", ["-DLBM_COL_T=float"], "lbm_col_f32.o")]
+                 ("lbm_col.hip", ["-DLBM_COL_T=double"], "lbm_col_f64.o"), ("lbm_col.hip", ["-DLBM_COL_T=float"], "lbm_col_f32.o"),
+                 ("lbm_col.hip", ["-DLBM_COL_TALL=1"], "lbm_col_tall_c.o"), ("lbm_col.hip", ["-DLBM_COL_TALL=0"], "lbm_col_tall_s.o")]
         common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", "-pthread", "-c"]
         procs, objs = [], []
         for src, extra, oname in units:

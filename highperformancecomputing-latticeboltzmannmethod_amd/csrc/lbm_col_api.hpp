@@ -24,8 +24,12 @@ constexpr int col_tile_w(int depth) { return 64 - 2 * (depth - 1); }
 constexpr int col_tile_h(int depth, int rows_per_thread) { return rows_per_thread * COL_NW - 2 * (depth - 1); }
 
 // k_stepc_col<T, rows per thread, COL_NW, depth, nt, arith> over the rows a.y_lo.. / a.y_lo2.. of the launch: depth 5, 6 or 7 on
-// 64 x 32 regions; tall (fp32; plain stores only — non-temporal ones cost 14 % there): depth 6, 7 or 8
+// 64 x 32 regions (one object file per element type: lbm_col.hip -DLBM_COL_T=double / float)
 template <typename T>
-void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool contracted, bool tall, hipStream_t s);
+void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool contracted, hipStream_t s);
+// ... and on the tall fp32 regions, depth 6, 7 or 8, plain stores only (non-temporal ones cost 14 % there); one object file per
+// arithmetic mode (lbm_col.hip -DLBM_COL_TALL=1 contracted / 0 strict: eight unrolled rows x up to eight levels compile slowly)
+void launch_col_tall_contracted(const KArgs<float>& a, const K2Extra<float>& e, int depth, hipStream_t s);
+void launch_col_tall_strict(const KArgs<float>& a, const K2Extra<float>& e, int depth, hipStream_t s);
 
 }  // namespace lbmk

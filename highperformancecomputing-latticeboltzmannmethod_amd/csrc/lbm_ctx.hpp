@@ -123,7 +123,7 @@ struct lbm_ctx {
     double feq_in[Q];
     int cyl_x = 0, cyl_y = 0, cyl_r = 0;
     // options
-    int variant = 0;     // single-iteration kernel: 0 = k_step_vec when nx % V == 0, 1 = k_step_site
+    int variant = 0;     // (unused since round 4: it chose the retired k_step_vec; the option is accepted so that old plan strings still load)
     int alternate = 1;   // walk the rows bottom-up / top-down on alternate steps (Infinity Cache reuse)
     int use_nt = 0;      // non-temporal stores in the step kernel
     int use_ntl = 0;     // non-temporal level-1 loads in the register kernel (k_stepc_col)

@@ -652,7 +652,7 @@ long lbm_graph_replays(const lbm_ctx* c) { return c ? c->graph_replays : 0; }
 const char* lbm_kernel_name(const lbm_ctx* c) {
     if (!c) return "";
     static thread_local char name[96];
-    snprintf(name, sizeof(name), "%s", plan_kernel_name(c->fuse, c->deep, c->pair_ty, c->use_nt, c->arith, (int)c->esize, use_vec(c)).c_str());
+    snprintf(name, sizeof(name), "%s", plan_kernel_name(c->fuse, c->deep, c->pair_ty, c->use_nt, c->arith, (int)c->esize).c_str());
     return name;
 }
 
@@ -662,13 +662,12 @@ int lbm_debug_plan_candidates(int nx, int ny, int precision, int arith, int num_
     if (!out || cap < 1 || nx < 1 || ny < 1) return fail(LBM_ERR_ARG, "bad argument");
     PlanQuery q;
     q.nx = nx; q.nyl = ny; q.ny_glob = ny; q.esize = precision == LBM_PRECISION_F32 ? 4 : 8; q.num_cus = num_cus > 0 ? num_cus : 256;
-    q.vec_ok = nx % (16 / q.esize) == 0;
     const Plan none{};
     std::string text;
     for (const Plan& pl : plan_candidates(q, none)) {
         const int fuse = pl.fuse > 0 ? pl.fuse : 1;
         text += pl.name + "|" + plan_option_string(pl.layout, pl.variant, pl.nt, pl.alternate, pl.ty, pl.xcd, fuse, pl.deep, pl.ntl) + "|" +
-                plan_kernel_name(fuse, pl.deep, pl.ty ? pl.ty : 8, pl.nt, arith, q.esize, pl.variant == 0 && q.vec_ok) + "|" + std::to_string(pl.deep ? deep_depth(pl.deep) : fuse) + "\n";
+                plan_kernel_name(fuse, pl.deep, pl.ty ? pl.ty : 8, pl.nt, arith, q.esize) + "|" + std::to_string(pl.deep ? deep_depth(pl.deep) : fuse) + "\n";
     }
     if ((int)text.size() + 1 > cap) return fail(LBM_ERR_ARG, "buffer too small (%zu bytes needed)", text.size() + 1);
     memcpy(out, text.c_str(), text.size() + 1);

@@ -21,7 +21,7 @@
 // its nine pulls and writes fluid interior cells only.
 //
 // Kernel families (within one arithmetic mode all evaluate the SAME per-cell operation sequence => bit-identical results):
-//   k_step_site / k_step_vec     one iteration per launch, 144 B of HBM traffic per lattice update (fp64)
+//   k_step_site                  one iteration per launch, 144 B of HBM traffic per lattice update (fp64)
 //   k_step2/3/4_tile             two / three / four iterations per launch over 64 x TY tiles, intermediate states in LDS
 //                                (what a call's last iterations, short strips and the strict mode's measurement use)
 //   k_stepd_tile                 six / seven / eight iterations on an LDS-filling tile: grids of a single round of blocks
@@ -306,7 +306,7 @@ __device__ __forceinline__ bool any_unstable(const T (&f)[Q]) {
 
 enum StepMode { MODE_STEP = 0, MODE_COLLIDE_ONLY = 1, MODE_STREAM_ONLY = 2 };
 
-// Baseline hot kernel: one thread per lattice site, block = 256 sites of one row (4 waves), 8-byte (fp64) /
+// One iteration per launch: one thread per lattice site, block = 256 sites of one row (4 waves), 8-byte (fp64) /
 // 4-byte (fp32) coalesced plane accesses; the x±1 pulls are the same coalesced stream shifted by one element.
 //   MODE_STEP         : K_t as described at the top of this file.
 //   MODE_COLLIDE_ONLY : collision_step of iteration 0 on the initial state (no pull, no BC, no stability test).
@@ -354,74 +354,9 @@ __global__ void __launch_bounds__(256) k_step_site(const KArgs<T> a) {
     }
 }
 
-// Production hot kernel: V = 16 B / sizeof(T) consecutive sites per thread (2 fp64 / 4 fp32), so every plane
-// access is one 16-byte-per-lane instruction (global_load/store_dwordx4): the three cx = 0 planes and all nine
-// stores are naturally aligned, the six cx = +-1 planes are the same stream displaced by one element
-// (element-aligned dwordx4; the displaced wave touches 9 instead of 8 128-B lines, the extra one is shared with
-// its neighbour through L2). Requires nx % V == 0; other widths use k_step_site. Solid sites inside a vector are
-// rewritten with w_i, which is what they hold already (N4), so the stores stay full-width.
-template <typename T, int V, int MODE, bool NT = false, int AR = AR_STRICT>
-__global__ void __launch_bounds__(256) k_step_vec(const KArgs<T> a) {
-    typedef T VA __attribute__((ext_vector_type(V)));                       // naturally aligned vector
-    typedef T VU __attribute__((ext_vector_type(V), aligned(sizeof(T))));   // element-aligned vector
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * V;
-    const int y = row_of_block(a);
-    if (x0 >= a.nx) return;
-    const int yg = a.y_start + y;
-    const long c = (long)(y + GR) * a.pitch + a.xoff + x0;
-    VA fv[Q];
-#pragma unroll
-    for (int i = 0; i < Q; ++i) {
-        const long off = (MODE == MODE_COLLIDE_ONLY) ? 0 : (long)cy(i) * a.pitch + cx(i);
-        const T* p = a.src + (long)i * a.plane + c - off;
-        if (MODE == MODE_COLLIDE_ONLY || cx(i) == 0) fv[i] = *reinterpret_cast<const VA*>(p);
-        else {
-            const VU u = *reinterpret_cast<const VU*>(p);
-#pragma unroll
-            for (int k = 0; k < V; ++k) fv[i][k] = u[k];
-        }
-    }
-    bool bad = false;
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-        const int x = x0 + k;
-        T f[Q];
-#pragma unroll
-        for (int i = 0; i < Q; ++i) f[i] = fv[i][k];
-        const bool solid = is_solid_cell(x, yg, a.cyl_x, a.cyl_y, a.cyl_r2);
-        if (MODE != MODE_COLLIDE_ONLY) {
-            T rho_bc, u_out;
-            if (!solid)
-                apply_bcs(f, yg == 0, yg == a.ny_glob - 1, x == 0, x == a.nx - 1, a.u_in, rho_bc, u_out);
-        }
-        if (MODE == MODE_STEP) bad |= any_unstable(f);
-        if (MODE == MODE_STREAM_ONLY) {
-            if (solid) {
-                T r[Q];
-#pragma unroll
-                for (int i = 0; i < Q; ++i) r[i] = f[opp(i)];
-#pragma unroll
-                for (int i = 0; i < Q; ++i) f[i] = r[i];
-            }
-        } else if (solid) {
-#pragma unroll
-            for (int i = 0; i < Q; ++i) f[i] = wgt<T>(i);
-        } else {
-            bgk_collide<T, AR>(f, a.tau_inv);
-        }
-#pragma unroll
-        for (int i = 0; i < Q; ++i) fv[i][k] = f[i];
-    }
-    if (MODE == MODE_STEP) {
-        if (bad) atomicMin(a.unstable_t, *a.t_base + a.t);
-    }
-#pragma unroll
-    for (int i = 0; i < Q; ++i) {
-        VA* p = reinterpret_cast<VA*>(a.dst + (long)i * a.plane + c);
-        if (NT) __builtin_nontemporal_store(fv[i], p);
-        else *p = fv[i];
-    }
-}
+// (Rounds 1-3 also had k_step_vec, the same step with 16 bytes per lane — two fp64 / four fp32 sites per thread: 110 us per iteration
+// at 4096x1024 fp64 against 112 for this kernel and 100 for this kernel with non-temporal stores; no measured plan ever took it. Retired
+// in round 4 with its 14 instantiations; option "variant" is accepted and ignored.)
 
 // Two timesteps per launch: temporal blocking through LDS. A block owns a TX x TY tile of outputs at iteration
 // t+1. Phase 1 computes P_{t+1} on the (TX+2) x (TY+2) region around it from global P_t — the step kernel's

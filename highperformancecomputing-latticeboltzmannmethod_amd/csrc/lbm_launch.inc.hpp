@@ -29,15 +29,6 @@ KArgs<T> make_kargs(const lbm_ctx* c, int src, int dst, int t) {
     return a;
 }
 
-template <typename T> constexpr int vec_width() { return (int)(16 / sizeof(T)); }
-
-// true: the 16-byte-per-lane kernel k_step_vec runs; false: the generic one-site-per-thread k_step_site
-inline bool use_vec(const lbm_ctx* c) {
-    const int v = (int)(16 / c->esize);
-    if (c->variant == 1) return false;
-    return c->nx % v == 0;
-}
-
 // Strides of the two layouts. Planar: plane stride = whole rows rounded up to k*64 KiB + 4 KiB (nine planes whose
 // stride is a multiple of 64 KiB put the nine accesses of a wave on the same HBM channel group: 5.2-5.4 TB/s at +0
 // vs 5.9-6.1 TB/s at +1..8 KiB, 4096x1024 fp64). Row-interleaved: the nine sub-rows of a lattice row are adjacent.
@@ -61,13 +52,10 @@ inline size_t buffer_bytes(const lbm_ctx* c) { return c->total * c->esize + 256;
 // policies and both arithmetic modes, MODE_COLLIDE_ONLY in both arithmetic modes, MODE_STREAM_ONLY once (no collision in it).
 template <typename T, int MODE>
 void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
-    constexpr int V = vec_width<T>();
     const bool nt = (MODE == MODE_STEP) && c->use_nt;
     const bool fast = (MODE != MODE_STREAM_ONLY) && c->arith == AR_CONTRACTED;
-    const bool vec = use_vec(c);
-    const dim3 grid(vec ? (c->nx / V + 255) / 256 : (c->nx + 255) / 256, a.y_cnt + a.y_cnt2), block(256);
-#define LBM_K1(NT_, AR_) do { if (vec) hipLaunchKernelGGL((k_step_vec<T, V, MODE, NT_, AR_>), grid, block, 0, s, a); \
-                              else hipLaunchKernelGGL((k_step_site<T, MODE, NT_, AR_>), grid, block, 0, s, a); } while (0)
+    const dim3 grid((c->nx + 255) / 256, a.y_cnt + a.y_cnt2), block(256);
+#define LBM_K1(NT_, AR_) hipLaunchKernelGGL((k_step_site<T, MODE, NT_, AR_>), grid, block, 0, s, a)
     if constexpr (MODE == MODE_STEP) {
         if (fast) { if (nt) LBM_K1(true, AR_CONTRACTED); else LBM_K1(false, AR_CONTRACTED); }
         else { if (nt) LBM_K1(true, AR_STRICT); else LBM_K1(false, AR_STRICT); }
@@ -103,7 +91,13 @@ void launch_fused_rows(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream
     e.ntl = c->use_ntl;
     const bool fast = c->arith == AR_CONTRACTED;
     if (c->deep_now && deep_is_col(shape)) {    // D iterations with the lattice in registers (k_stepc_col, lbm_col.hip)
-        launch_col<T>(a, e, depth, c->use_nt != 0, fast, deep_is_tall(shape), s);
+        if constexpr (sizeof(T) == 4) {
+            if (deep_is_tall(shape)) {
+                if (fast) launch_col_tall_contracted(a, e, depth, s); else launch_col_tall_strict(a, e, depth, s);
+                return;
+            }
+        }
+        launch_col<T>(a, e, depth, c->use_nt != 0, fast, s);
         return;
     }
     if (c->deep_now) {    // D iterations on a deep LDS tile (k_stepd_tile; whole-domain launches of small grids)

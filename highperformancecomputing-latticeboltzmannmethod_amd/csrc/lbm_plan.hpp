@@ -11,7 +11,7 @@
 
 namespace lbmk {
 
-// layout 0 planar / 1 row-interleaved; variant 0 k_step_vec / 1 k_step_site for single iterations; nt: non-temporal stores;
+// layout 0 planar / 1 row-interleaved; variant: unused since round 4 (it chose between k_step_vec, retired, and k_step_site); nt: non-temporal stores;
 // alternate: walk direction alternates per launch; fuse: iterations per launch of the tile kernels (1..4) or of the deep shape;
 // ty: tile height of the two- / three-iteration tile kernels (8 or 12); xcd: XCD-aware tile walk; deep: 0, or the deep shape
 // (1..3: k_stepd_tile six / seven / eight iterations; 6 / 7: k_stepc_col five / six iterations in registers on 64x32 regions;
@@ -39,7 +39,6 @@ struct PlanQuery {
     int nstrips = 1;                    // strips of the run (ranks or group members)
     bool strips = false;                // this context has (or simulates) strip faces
     bool faces = false;                 // ... and at least one of them is an internal face
-    bool vec_ok = false;                // nx is a multiple of the 16-byte vector width
     bool tune = true, can_tune = true;  // option "tune"; the grid is neither too small nor too large to measure
 };
 
@@ -65,7 +64,7 @@ inline std::vector<Plan> plan_candidates(const PlanQuery& q, const Plan& fixed) 
     if (!q.can_tune) {
         if (strip_deep) cand.push_back({1, 1, 1, 0, 6, 12, 1, deep_name + " (default, not measured)", strip_deep});
         else if (q.strips) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved (default, not measured)"});
-        else cand.push_back({0, q.vec_ok ? 0 : 1, 1, 0, 3, 12, 0, "planar (default, not measured)"});
+        else cand.push_back({0, 1, 1, 0, 3, 12, 0, "planar (default, not measured)"});
         return cand;
     }
     // Strips exchange GR rows x 9 sub-rows as one contiguous run: row-interleaved only. Every rank must issue the same
@@ -123,22 +122,20 @@ inline std::vector<Plan> plan_candidates(const PlanQuery& q, const Plan& fixed) 
     cand.push_back({0, 0, 1, 0, 3, 12, 0, "planar/3-step 64x12/nt-store"});
     cand.push_back({0, 0, 1, 0, 2, 12, 0, "planar/2-step 64x12/nt-store"});
     cand.push_back({0, 0, 0, 1, 3, 12, 0, "planar/3-step 64x12/alternate"});
-    if (q.vec_ok) cand.push_back({0, 0, 0, 1, 1, 0, 0, "planar/vec16B/alternate"});
     cand.push_back({0, 1, 0, 1, 1, 0, 0, "planar/site/alternate"});
     return cand;
 }
 
 // the dominant kernel of a plan, as rocprofv3 names it (minus "lbmk::" and blanks)
-inline std::string plan_kernel_name(int fuse, int deep, int pair_ty, int nt, int arith, int esize, bool vec) {
+inline std::string plan_kernel_name(int fuse, int deep, int pair_ty, int nt, int arith, int esize) {
     char name[96];
     const char* t = esize == 4 ? "float" : "double";
-    const bool tall = deep_is_tall(deep) && esize == 4;      // (tall regions: plain stores only)
-    const char* nts = nt && !tall ? "true" : "false";
+    const bool tall = deep_is_tall(deep) && esize == 4;      // (tall regions and seven-iteration launches: plain stores only)
+    const char* nts = nt && !tall && !(deep_is_col(deep) && deep_depth(deep) == 7) ? "true" : "false";
     if (fuse > 2 && deep_is_col(deep)) snprintf(name, sizeof(name), "k_stepc_col<%s,%d,%d,%d,%s,%d>", t, col_rows_per_thread(esize, arith == 0, tall), COL_NW, deep_depth(deep), nts, arith);
     else if (fuse > 2 && deep) snprintf(name, sizeof(name), "k_stepd_tile<%s,%s,%d,%d>", t, deep_tile(deep), deep_depth(deep), arith);
     else if (fuse == 4) snprintf(name, sizeof(name), "k_step4_tile<%s,8,%d,%d>", t, esize == 8 ? 1024 : 512, arith);
     else if (fuse > 1) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%d>", fuse, t, pair_ty, pair_ty == 12 ? (fuse == 3 ? 1024 : 768) : 512, arith);
-    else if (vec) snprintf(name, sizeof(name), "k_step_vec<%s,%d,0,%s,%d>", t, 16 / esize, nts, arith);
     else snprintf(name, sizeof(name), "k_step_site<%s,0,%s,%d>", t, nts, arith);
     return name;
 }

@@ -54,7 +54,6 @@ int choose_plan(lbm_ctx* c) {
                         "fixed by options", c->deep, c->use_ntl};
     const bool p2 = pair_possible(c);
     (void)p2;
-    const bool vec_ok = (c->nx % vec_width<T>() == 0);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     configure_layout(c, 1);
@@ -66,7 +65,7 @@ int choose_plan(lbm_ctx* c) {
     const int nstrips = c->group_n > 1 ? c->group_n : (c->comm && c->nranks > 1) ? c->nranks : 1;
     PlanQuery q;
     q.nx = c->nx; q.nyl = c->nyl; q.ny_glob = c->p.ny; q.esize = (int)c->esize; q.num_cus = c->num_cus; q.nstrips = nstrips; q.strips = strips;
-    q.vec_ok = vec_ok; q.tune = c->tune != 0; q.can_tune = can_tune; q.faces = face_south(c) || face_north(c);
+    q.tune = c->tune != 0; q.can_tune = can_tune; q.faces = face_south(c) || face_north(c);
     const std::vector<Plan> cand = plan_candidates(q, fixed);
     free_buffers(c);                                // a second lbm_initialise starts from no population buffers
     // First round: every candidate once; the three fastest keep their allocations. Final round: those three again with

@@ -164,7 +164,7 @@ int  lbm_load_state(lbm_ctx* c, const char* path);
 
 /* Tuning/diagnostics (not part of the reference surface). Keys, all to be set before lbm_initialise:
  *   "tune" 1|0    time the candidate plans at lbm_initialise and keep the fastest (default 1); with 0 the plan is
- *                 "layout" 0 planar|1 row-interleaved, "variant" 0 16-B-per-lane kernel|1 one site per thread,
+ *                 "layout" 0 planar|1 row-interleaved, "variant" (accepted and ignored since round 4: the 16-B-per-lane kernel it selected is retired),
  *                 "nt" non-temporal stores, "ntl" non-temporal level-1 loads of the register kernel ("deep" 6 / 7),
  *                 "alternate" alternate the row walk direction per launch,
  *                 "fuse" 1|2|3|4 iterations fused per launch through LDS (k_step2_tile / k_step3_tile / k_step4_tile, the
