@@ -35,6 +35,14 @@ struct Lattice {
     double u_in;
     int cur = 0;      // buffer holding the current state (0 = A)
     int t = 0;
+    // pipelined launches (pipe_variant): one stream per part of the lattice, one event per part and step parity
+    hipStream_t ps[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pe[2][4];
+    int pstep = 0;
+    void pipe_init() {
+        if (ps[0]) return;
+        for (int p = 0; p < 4; ++p) { CK(hipStreamCreateWithFlags(&ps[p], hipStreamNonBlocking)); for (int k = 0; k < 2; ++k) CK(hipEventCreateWithFlags(&pe[k][p], hipEventDisableTiming)); }
+    }
     Lattice(int nx_, int ny_) : nx(nx_), ny(ny_) {
         const int per128 = 128 / sizeof(T);
         xoff = per128;
@@ -76,7 +84,7 @@ struct Lattice {
         hipLaunchKernelGGL((k_init<T>), dim3((nx + 2 + 255) / 256, ny + 2 * GR), dim3(256), 0, s, ia);
         const int big = 0x7fffffff;
         CK(hipMemcpyAsync(d_unst, &big, sizeof(int), hipMemcpyHostToDevice, s));
-        cur = 0; t = 0;
+        cur = 0; t = 0; pstep = 0;
         // iteration 0's collision: A -> B
         KArgs<T> a = args(0);
         hipLaunchKernelGGL((k_step_site<T, MODE_COLLIDE_ONLY, false, AR_CONTRACTED>), dim3((nx + 255) / 256, ny), dim3(256), 0, s, a);
@@ -108,6 +116,39 @@ Variant<T> col_variant(bool nt, bool alt = false, int persist = 0) {
         a.reverse = alt ? (L.cur & 1) : 0;       // walk the tile rows top-down on every other launch
         if (nt) hipLaunchKernelGGL((k_stepc_col<T, R, NW, D, true, AR>), grid, dim3(NW * 64), 0, L.s, a, L.extra());
         else hipLaunchKernelGGL((k_stepc_col<T, R, NW, D, false, AR>), grid, dim3(NW * 64), 0, L.s, a, L.extra());
+    }};
+}
+// PIPELINED launches: the lattice in P parts of whole tile rows, one kernel and one stream per part; part p of launch n+1 waits for
+// parts p-1, p, p+1 of launch n only (its inputs, and the readers of the rows it overwrites), so it starts while the last part of
+// launch n is still draining: the ramp of one launch fills the drain of the other.
+template <typename T, int R, int NW, int D, int AR>
+Variant<T> pipe_variant(int P, bool alt = false) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "pipe%d R=%d NW=%d D=%d %s", P, R, NW, D, alt ? "alt" : "");
+    return {nm, D, [=](Lattice<T>& L) {
+        constexpr int OW = 64 - 2 * (D - 1), OH = R * NW - 2 * (D - 1);
+        L.pipe_init();
+        const int trows = (L.ny + OH - 1) / OH, nbx = (L.nx + OW - 1) / OW;
+        const int par = L.pstep & 1, prev = par ^ 1;
+        for (int k = 0; k < P; ++k) {
+            const int p = (alt && (L.pstep & 1)) ? P - 1 - k : k;
+            const int tr0 = trows * p / P, tr1 = trows * (p + 1) / P;
+            const int y0 = tr0 * OH, y1 = std::min(L.ny, tr1 * OH);
+            if (y1 <= y0) continue;
+            hipStream_t st = L.ps[p];
+            if (L.pstep > 0) {
+                if (p > 0) CK(hipStreamWaitEvent(st, L.pe[prev][p - 1], 0));
+                if (p + 1 < P) CK(hipStreamWaitEvent(st, L.pe[prev][p + 1], 0));
+            }
+            KArgs<T> a = L.args(L.t);
+            a.y_lo = y0; a.y_cnt = y1 - y0;
+            a.reverse = alt ? (L.pstep & 1) : 0;
+            const int nb = nbx * (tr1 - tr0);
+            hipLaunchKernelGGL((k_stepc_col<T, R, NW, D, false, AR>), dim3((nb + 7) / 8 * 8), dim3(NW * 64), 0, st, a, L.extra());
+            CK(hipEventRecord(L.pe[par][p], st));
+            CK(hipStreamWaitEvent(L.s, L.pe[par][p], 0));
+        }
+        ++L.pstep;
     }};
 }
 // the sliding form (lbm_kernel_slide.hpp): the host deals the segments (lbm_slide_plan.hpp); slots = resident blocks to plan for
@@ -186,6 +227,10 @@ std::vector<Variant<T>> variants() {
         v.push_back(col_variant<T, 8, 8, 8, AR>(false, true));
         v.push_back(col_variant<T, 8, 8, 8, AR>(true, true));
     }
+    v.push_back(pipe_variant<T, 4, 8, 6, AR>(2));
+    v.push_back(pipe_variant<T, 4, 8, 6, AR>(3));
+    v.push_back(pipe_variant<T, 4, 8, 6, AR>(4));
+    v.push_back(pipe_variant<T, 4, 8, 6, AR>(3, true));
     v.push_back(slide_variant<T, 4, 8, 6, AR>(false));
     v.push_back(slide_variant<T, 4, 8, 6, AR>(true));
     v.push_back(slide_variant<T, 4, 8, 5, AR>(false));
