@@ -162,3 +162,58 @@ def test_random_case_matches_oracle(case):
         assert [r[0] for r in log] == [r[0] for r in ref_forces]
         for (t, fx, fy), r in zip(log, ref_forces):
             assert abs(fx - r[1]) <= 1e-10 * fscale and abs(fy - r[2]) <= 1e-10 * fscale
+
+
+def fp32_cases(n=24, seed=20261004):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        nx = int(rng.choice([rng.integers(2, 60), rng.integers(60, 200), rng.integers(200, 500), 50, 52, 53, 64, 104, 128]))
+        ny = int(rng.choice([rng.integers(2, 30), rng.integers(30, 120), rng.integers(120, 260), 36, 38, 50, 52, 64, 104]))
+        tau = float(rng.uniform(0.56, 1.2))
+        u = float(rng.uniform(0.005, 0.09))
+        cyl = rng.integers(0, 6)
+        cx, cy, cr = [(0.2, 0.5, 0.05), (-1.0, 0.5, 0.0), (0.0, 0.5, 0.15), (0.5, 0.0, 0.2), (0.0, 0.0, 0.3), (0.98, 0.5, 0.25)][cyl]
+        steps = int(rng.integers(1, 120))
+        of = int(rng.integers(1, 50))
+        arith = int(rng.integers(0, 2))
+        opts = dict(tune=0, layout=int(rng.integers(0, 2)), variant=1, nt=0, alternate=int(rng.integers(0, 2)), pair_ty=12,
+                    xcd=int(rng.integers(0, 2)), deep=8, arith=arith, trailing_pair=int(rng.integers(0, 2)))
+        strips = min(int(rng.integers(2, 4)), ny // 12) if ny >= 40 and k % 2 else 1
+        if strips > 1:
+            opts.update(layout=1, alternate=0, overlap=int(rng.integers(0, 3)), group_threads=int(rng.integers(0, 2)))
+        out.append((k, nx, ny, tau, u, cx, cy, cr, steps, of, opts, strips))
+    return out
+
+
+@pytest.mark.parametrize("case", fp32_cases(), ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}" + ("-fast" if c[10]["arith"] else "") + (f"-{c[11]}strips" if c[11] > 1 else ""))
+def test_random_fp32_tall_regions_match_one_launch_per_iteration(case):
+    """fp32 has no oracle (the reference is fp64): the tall register shape ("deep" 8: 64x64 regions, strict arithmetic 64x48; seven
+    iterations per launch, six / eight for remainders) is held bit for bit to one k_step_site launch per iteration in the same
+    arithmetic on random ragged grids — whole domains and groups of strips; the fp32 path itself is held to the fp64 oracle at a
+    stated tolerance in tests/test_gpu_parity.py."""
+    lbm = importlib.import_module(PKG)
+    k, nx, ny, tau, u, cx, cy, cr, steps, of, opts, strips = case
+    kw = dict(tau=tau, inlet_velocity=u, cylinder_x=cx, cylinder_y=cy, cylinder_radius=cr, precision="f32")
+    with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1, arith=opts["arith"]), **kw) as ref:
+        ref.initialise()
+        ref.step(steps, of)
+        r_bad, r_fn, r_log = ref.first_unstable_step(), ref.populations("f_next"), ref.drain_force_log()
+    with (lbm.Group(nx, ny, strips, options=opts, **kw) if strips > 1 else lbm.Context(nx, ny, options=opts, **kw)) as ctx:
+        ctx.initialise()
+        if opts.get("trailing_pair") and steps > 1:
+            ctx.step(steps - 1, of)
+            ctx.step(1, of)
+        else:
+            ctx.step(steps, of)
+        assert ctx.first_unstable_step() == r_bad
+        if r_bad != -1:
+            return
+        assert np.array_equal(ctx.populations("f_next"), r_fn)
+        log = ctx.drain_force_log()
+        assert [r[0] for r in log] == [r[0] for r in r_log]
+        for (t, fx, fy), (_, wx, wy) in zip(log, r_log):
+            if strips == 1:
+                assert fx == wx and fy == wy
+            else:       # (the strips' partial sums are added in another order)
+                assert abs(fx - wx) <= 1e-5 * max(1.0, abs(wx)) and abs(fy - wy) <= 1e-5 * max(1.0, abs(wy))
