@@ -6,24 +6,29 @@
 
 namespace lbmk {
 
-constexpr int COL_NW = 8;                 // waves per block; two blocks per CU
-// rows per thread: 4 (a 64 x 32 region) — except fp64 STRICT arithmetic, whose collision needs a dozen more live registers than
-// 128 VGPRs leave beside 4 x 9 fp64 populations: 3 rows (64 x 24), 122 VGPRs, no scratch. Round 3's strict kernels spilled 12
-// VGPRs (44 B of scratch per lane, 20 % more HBM writes); measured at 4096x1024 (tools/colbench, round 4): 129.9 GLUPS on
-// 3 rows x five iterations against 106-114 on 4 rows. Contracted arithmetic is faster on 4 rows (158-163 against 145-150).
+// Waves per block and rows per thread (the region is 64 columns x waves * rows): 8 waves x 4 rows = 64 x 32, two blocks per CU —
+// except fp64 STRICT arithmetic, whose collision needs a dozen more live registers than 128 VGPRs leave beside 4 x 9 fp64
+// populations. Round 4 first ran it on 8 waves x 3 rows (64 x 24, 122 VGPRs, no scratch: 106-114 -> 127-130 GLUPS at 4096x1024; round
+// 3's 4-row kernels spilled 12 VGPRs), then on the same 64 x 24 region as 12 waves x 2 rows: 70 VGPRs = six waves per SIMD = two blocks
+// of 12 waves = 24 waves per CU instead of 16: 135.7 against 127.3 GLUPS (tools/colbench --strict). Contracted arithmetic is fastest
+// on 8 x 4 (64 x 24 on 24 waves: 157-159 against 158-162; 8 x 3: 146-150).
+constexpr int col_waves(int esize, bool strict, bool tall = false) { return (esize == 8 && strict && !tall) ? 12 : 8; }
 // TALL (fp32 only, round 4): 8 rows per thread, a 64 x 64 region. Nine fp32 populations x 8 rows are 72 registers — what 4 fp64
 // rows take — so the tall block also runs two per CU (121-127 VGPRs), but stores 52 x 52 of 64 x 64 cells at seven iterations where
 // the 64 x 32 region stores 54 x 22 at six: 1.19 x instead of 1.45 x the lattice read per launch, 17 % fewer redundant collisions.
 // 16384x4096 fp32 (tools/colbench): 311 GLUPS at seven iterations, 302 at six / eight, against 289-292 on 64 x 32; at 4096x1024 (three
 // rounds of blocks) it loses, 217-226 against 263 — a measured candidate, never a rule. fp32 strict: 6 rows (64 x 48).
 constexpr int col_rows_per_thread(int esize, bool strict, bool tall = false) {
-    return tall && esize == 4 ? (strict ? 6 : 8) : (esize == 8 && strict) ? 3 : 4;
+    return tall && esize == 4 ? (strict ? 6 : 8) : (esize == 8 && strict) ? 2 : 4;
 }
 // output tile of a launch of `depth` iterations
 constexpr int col_tile_w(int depth) { return 64 - 2 * (depth - 1); }
-constexpr int col_tile_h(int depth, int rows_per_thread) { return rows_per_thread * COL_NW - 2 * (depth - 1); }
+constexpr int col_tile_h(int depth, int rows_per_thread, int waves) { return rows_per_thread * waves - 2 * (depth - 1); }
+constexpr int col_tile_h(int depth, int esize, bool strict, bool tall) {
+    return col_tile_h(depth, col_rows_per_thread(esize, strict, tall), col_waves(esize, strict, tall));
+}
 
-// k_stepc_col<T, rows per thread, COL_NW, depth, nt, arith> over the rows a.y_lo.. / a.y_lo2.. of the launch: depth 5, 6 or 7 on
+// k_stepc_col<T, rows per thread, waves, depth, nt, arith> over the rows a.y_lo.. / a.y_lo2.. of the launch: depth 5, 6 or 7 on
 // 64 x 32 regions (one object file per element type: lbm_col.hip -DLBM_COL_T=double / float)
 template <typename T>
 void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool contracted, hipStream_t s);

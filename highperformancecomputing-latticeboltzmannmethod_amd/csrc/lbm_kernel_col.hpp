@@ -46,8 +46,9 @@ __device__ __forceinline__ float from_left(float v) { return __builtin_bit_cast(
 __device__ __forceinline__ float from_right(float v) { return __builtin_bit_cast(float, dpp_shl1(__builtin_bit_cast(unsigned, v))); }
 
 // (in-kernel phase record, tools/colbench -DLBM_COL_PROF only: LBM_PROF / LBM_PROF_IDS, lbm_kernels.hpp)
-// waves per SIMD the register allocation may assume: two blocks per CU when they fit 32 waves, else one
-template <int NW> constexpr int col_waves_per_simd() { return NW <= 8 ? (2 * NW) / 4 : NW / 4; }
+// waves per SIMD the register allocation may assume: two blocks per CU when they fit 32 waves (8 waves: four per SIMD, 128 VGPRs;
+// 12 waves: six per SIMD, 80 VGPRs — the two-row fp64 strict shape), else one
+template <int NW> constexpr int col_waves_per_simd() { return NW == 12 ? 6 : NW <= 8 ? (2 * NW) / 4 : NW / 4; }
 
 // stability verdict of one cell, counted only where `valid` (garbage cells may hold anything, NaN included)
 template <typename T>
@@ -84,9 +85,10 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
     constexpr int H = R * NW, HW = D - 1, OW = 64 - 2 * HW, OH = H - 2 * HW, LW = 64 + 2;
     static_assert(D >= 2 && OH >= 1 && R >= 2, "(D <= GR on a strip: its ghost rows go GR deep — the host's business)");
     // exchange buffer: per wave the three north-going populations of its top row and the three south-going ones of its
-    // bottom row; slots 0 and NW+1 stand for the neighbours the first / last wave does not have (never written: garbage
-    // for cells that are garbage anyway); one pad column on each side for the diagonal reads at lane -/+ 1
-    __shared__ T xbuf[2][NW + 2][6][LW];
+    // bottom row; the first / last wave, which have no neighbour below / above, read their OWN slot instead (garbage for cells
+    // that are garbage anyway: round 4 dropped the two phantom slots, 63 -> 51 KB at 8 fp64 waves, so that 12 waves fit two
+    // blocks per CU); one pad column on each side for the diagonal reads at lane -/+ 1
+    __shared__ T xbuf[2][NW][6][LW];
     const int lane = (int)threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int nbx = (a.nx + OW - 1) / OW, nby = (a.y_cnt + OH - 1) / OH + (a.y_cnt2 + OH - 1) / OH, nb = nbx * nby;
@@ -168,11 +170,12 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
         // ---- levels 2..D: exchange with the neighbouring waves / lanes, then update in place (level D: store)
         auto level = [&]<int L>() {
             T (*xb)[6][LW] = xbuf[L & 1];
-            xb[w + 1][0][1 + lane] = g[R - 1][2]; xb[w + 1][1][1 + lane] = g[R - 1][5]; xb[w + 1][2][1 + lane] = g[R - 1][6];
-            xb[w + 1][3][1 + lane] = g[0][4];     xb[w + 1][4][1 + lane] = g[0][7];     xb[w + 1][5][1 + lane] = g[0][8];
+            const int wb = w > 0 ? w - 1 : 0, wa = w + 1 < NW ? w + 1 : NW - 1;
+            xb[w][0][1 + lane] = g[R - 1][2]; xb[w][1][1 + lane] = g[R - 1][5]; xb[w][2][1 + lane] = g[R - 1][6];
+            xb[w][3][1 + lane] = g[0][4];     xb[w][4][1 + lane] = g[0][7];     xb[w][5][1 + lane] = g[0][8];
             __syncthreads();
             // from the wave below (its top row): f2 at x, f5 at x-1, f6 at x+1; from the wave above (its bottom row): f4, f7 at x+1, f8 at x-1
-            T p2 = xb[w][0][1 + lane], p5 = xb[w][1][lane], p6 = xb[w][2][2 + lane];
+            T p2 = xb[wb][0][1 + lane], p5 = xb[wb][1][lane], p6 = xb[wb][2][2 + lane];
             bool badl = false;
             const bool lane_ok = lane >= L - 1 && lane <= 64 - L;
 #pragma unroll
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
                 f[0] = g[j][0]; f[1] = from_left(g[j][1]); f[3] = from_right(g[j][3]);
                 f[2] = p2; f[5] = p5; f[6] = p6;
                 if (j < R - 1) { f[4] = g[j + 1][4]; f[7] = from_right(g[j + 1][7]); f[8] = from_left(g[j + 1][8]); }
-                else { f[4] = xb[w + 2][3][1 + lane]; f[7] = xb[w + 2][4][2 + lane]; f[8] = xb[w + 2][5][lane]; }   // (read here, not after the barrier: six registers fewer are live across the rows below; the buffer is not rewritten before this wave has passed the next barrier)
+                else { f[4] = xb[wa][3][1 + lane]; f[7] = xb[wa][4][2 + lane]; f[8] = xb[wa][5][lane]; }   // (read here, not after the barrier: six registers fewer are live across the rows below; the buffer is not rewritten before this wave has passed the next barrier)
                 const bool valid = lane_ok;
                 const int y = Yr + ry, yg = a.y_start + y;
                 bool store = L == D && lane >= HW && lane < 64 - HW && ry >= HW && ry < H - HW;

@@ -69,14 +69,14 @@ void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
 
 // "deep" plans: shape id -> iterations per launch and tile. 1..3: LDS-image tiles (k_stepd_tile: six / seven iterations on
 // 64x16 tiles, eight on 32x32; what a grid of a single round of blocks picks); 6 / 7: the register-resident column kernel
-// (k_stepc_col, R = 4 rows per thread x 8 waves = a 64 x 32 region per block, two blocks per CU) with five / six iterations —
+// (k_stepc_col, R = 4 rows per thread x 8 waves = a 64 x 32 region per block, two blocks per CU; fp64 strict: 2 rows x 12 waves = 64 x 24) with five / six iterations —
 // a plan of either uses both depths, and on a context without strip faces seven iterations too, for what a segment leaves
 // over (20 = 7 + 7 + 6; at 4096x1024 fp64 seven iterations run at 160.6 GLUPS against 161.7 for six — eight, 154.3, are
 // not built); 9: the same family with seven iterations as the plan's depth (8192x2048 fp64: 175.9 against 169.9); 8: fp32 only, the same kernel on TALL 64 x 64 regions (eight rows per thread) with seven iterations, six / eight for
 // what a segment leaves over. Ids 4 / 5 were round 2's 32x16 LDS tiles: retired.
 // rows of one band of tiles of a launch of `depth` iterations (the edge bands of a strip are one band each)
 inline int deep_rows(const lbm_ctx* c, int id, int depth) {
-    if (deep_is_col(id)) return col_tile_h(depth, col_rows_per_thread((int)c->esize, c->arith == 0, deep_is_tall(id)));
+    if (deep_is_col(id)) return col_tile_h(depth, (int)c->esize, c->arith == 0, deep_is_tall(id));
     return id == 3 ? 32 : 16;
 }
 // A fused kernel over the local rows [a.y_lo, a.y_lo + a.y_cnt): iterations a.t .. a.t + depth - 1 (depth 2..8).

@@ -132,7 +132,7 @@ inline std::string plan_kernel_name(int fuse, int deep, int pair_ty, int nt, int
     const char* t = esize == 4 ? "float" : "double";
     const bool tall = deep_is_tall(deep) && esize == 4;      // (tall regions and seven-iteration launches: plain stores only)
     const char* nts = nt && !tall && !(deep_is_col(deep) && deep_depth(deep) == 7) ? "true" : "false";
-    if (fuse > 2 && deep_is_col(deep)) snprintf(name, sizeof(name), "k_stepc_col<%s,%d,%d,%d,%s,%d>", t, col_rows_per_thread(esize, arith == 0, tall), COL_NW, deep_depth(deep), nts, arith);
+    if (fuse > 2 && deep_is_col(deep)) snprintf(name, sizeof(name), "k_stepc_col<%s,%d,%d,%d,%s,%d>", t, col_rows_per_thread(esize, arith == 0, tall), col_waves(esize, arith == 0, tall), deep_depth(deep), nts, arith);
     else if (fuse > 2 && deep) snprintf(name, sizeof(name), "k_stepd_tile<%s,%s,%d,%d>", t, deep_tile(deep), deep_depth(deep), arith);
     else if (fuse == 4) snprintf(name, sizeof(name), "k_step4_tile<%s,8,%d,%d>", t, esize == 8 ? 1024 : 512, arith);
     else if (fuse > 1) snprintf(name, sizeof(name), "k_step%d_tile<%s,%d,%d,%d>", fuse, t, pair_ty, pair_ty == 12 ? (fuse == 3 ? 1024 : 768) : 512, arith);

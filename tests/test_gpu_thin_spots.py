@@ -48,7 +48,7 @@ def test_production_strip_rule_at_c4_size_8192x2048(lbm):
         assert g.initialise() == 32681
         plans = [m.plan() for m in g.ctxs]
         assert all("6-step 64x32 in registers" in p for p in plans), plans
-        assert all(m.kernel_name().startswith("k_stepc_col<double,3,8,") for m in g.ctxs)
+        assert all(m.kernel_name().startswith("k_stepc_col<double,2,12,") for m in g.ctxs)
         schedule = g.ctxs[0].strip_schedule()
         g.step(steps, of)
         assert g.first_unstable_step() == -1

@@ -214,6 +214,12 @@ std::vector<Variant<T>> variants() {
     v.push_back(col_variant<T, 3, 8, 5, AR>(true));
     v.push_back(col_variant<T, 3, 8, 6, AR>(true));
     v.push_back(col_variant<T, 3, 8, 6, AR>(false, true));
+    if constexpr (sizeof(T) == 8) {        // two fp64 rows per thread on 12 waves: the 64x24 region of the strict shape with 24 waves per CU
+        v.push_back(col_variant<T, 2, 12, 5, AR>(true));
+        v.push_back(col_variant<T, 2, 12, 5, AR>(false, true));
+        v.push_back(col_variant<T, 2, 12, 6, AR>(true));
+        v.push_back(col_variant<T, 2, 12, 6, AR>(false, true));
+    }
     if constexpr (sizeof(T) == 8) {        // fp64: 64x64 regions need 16 waves (one block per CU)
         v.push_back(col_variant<T, 4, 16, 6, AR>(false, true));
         v.push_back(col_variant<T, 4, 16, 7, AR>(false, true));
