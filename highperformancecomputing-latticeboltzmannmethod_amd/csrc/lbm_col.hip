@@ -27,15 +27,15 @@ void launch_col(const KArgs<T>& a, const K2Extra<T>& e, int depth, bool nt, bool
 #undef LBM_KD
 }
 template void launch_col<LBM_COL_T>(const KArgs<LBM_COL_T>&, const K2Extra<LBM_COL_T>&, int, bool, bool, hipStream_t);
-#elif defined(LBM_COL_TALL)  // the tall fp32 regions of one arithmetic mode: 64 x 64 contracted (1), 64 x 48 strict (0)
+#elif defined(LBM_COL_TALL)  // the tall fp32 regions (64 x 48) of one arithmetic mode: contracted 12 waves x 4 rows (1), strict 8 x 6 (0)
 #if LBM_COL_TALL
 void launch_col_tall_contracted(const KArgs<float>& a, const K2Extra<float>& e, int depth, hipStream_t s) {
-    constexpr int R = col_rows_per_thread(4, false, true), AR = AR_CONTRACTED;
+    constexpr int R = col_rows_per_thread(4, false, true), W = col_waves(4, false, true), AR = AR_CONTRACTED;
 #else
 void launch_col_tall_strict(const KArgs<float>& a, const K2Extra<float>& e, int depth, hipStream_t s) {
-    constexpr int R = col_rows_per_thread(4, true, true), AR = AR_STRICT;
+    constexpr int R = col_rows_per_thread(4, true, true), W = col_waves(4, true, true), AR = AR_STRICT;
 #endif
-    if (depth == 6) LBM_KC(float, 6, R, 8, false, AR); else if (depth == 8) LBM_KC(float, 8, R, 8, false, AR); else LBM_KC(float, 7, R, 8, false, AR);
+    if (depth == 6) LBM_KC(float, 6, R, W, false, AR); else if (depth == 8) LBM_KC(float, 8, R, W, false, AR); else LBM_KC(float, 7, R, W, false, AR);
 }
 #else
 #error "compile with -DLBM_COL_T=double, -DLBM_COL_T=float, -DLBM_COL_TALL=1 or -DLBM_COL_TALL=0"

@@ -12,14 +12,17 @@ namespace lbmk {
 // 3's 4-row kernels spilled 12 VGPRs), then on the same 64 x 24 region as 12 waves x 2 rows: 70 VGPRs = six waves per SIMD = two blocks
 // of 12 waves = 24 waves per CU instead of 16: 135.7 against 127.3 GLUPS (tools/colbench --strict). Contracted arithmetic is fastest
 // on 8 x 4 (64 x 24 on 24 waves: 157-159 against 158-162; 8 x 3: 146-150).
-constexpr int col_waves(int esize, bool strict, bool tall = false) { return (esize == 8 && strict && !tall) ? 12 : 8; }
-// TALL (fp32 only, round 4): 8 rows per thread, a 64 x 64 region. Nine fp32 populations x 8 rows are 72 registers — what 4 fp64
-// rows take — so the tall block also runs two per CU (121-127 VGPRs), but stores 52 x 52 of 64 x 64 cells at seven iterations where
-// the 64 x 32 region stores 54 x 22 at six: 1.19 x instead of 1.45 x the lattice read per launch, 17 % fewer redundant collisions.
-// 16384x4096 fp32 (tools/colbench): 311 GLUPS at seven iterations, 302 at six / eight, against 289-292 on 64 x 32; at 4096x1024 (three
-// rounds of blocks) it loses, 217-226 against 263 — a measured candidate, never a rule. fp32 strict: 6 rows (64 x 48).
+constexpr int col_waves(int esize, bool strict, bool tall = false) {
+    return (esize == 8 && strict && !tall) || (esize == 4 && tall && !strict) ? 12 : 8;
+}
+// TALL (fp32 only, round 4): a 64 x 48 region — 12 waves x 4 rows in contracted arithmetic (76 VGPRs = six waves per SIMD = two
+// blocks = 24 waves per CU, as many as three standard blocks), 8 waves x 6 rows in strict arithmetic (112-116 VGPRs). At seven
+// iterations it stores 52 x 36 of its 64 x 48 cells where the 64 x 32 region stores 54 x 22 at six: 1.33 x instead of 1.45 x the
+// lattice read per launch. 16384x4096 fp32 (tools/colbench): 320 GLUPS at seven iterations, 315 at six, against 289-298 on 64 x 32;
+// 4096x1024 262 against 260; a 16384x512 strip 259 against 246-260. The first tall shape of the round, 8 waves x 8 rows = 64 x 64
+// (121-127 VGPRs, 12 B of scratch), read 310 at 16384x4096 and lost elsewhere (216 at 4096x1024, 209 on the strip): replaced.
 constexpr int col_rows_per_thread(int esize, bool strict, bool tall = false) {
-    return tall && esize == 4 ? (strict ? 6 : 8) : (esize == 8 && strict) ? 2 : 4;
+    return tall && esize == 4 ? (strict ? 6 : 4) : (esize == 8 && strict) ? 2 : 4;
 }
 // output tile of a launch of `depth` iterations
 constexpr int col_tile_w(int depth) { return 64 - 2 * (depth - 1); }

@@ -599,9 +599,9 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "ntl") c->use_ntl = (int)value ? 1 : 0;
     else if (k == "fuse") { if (value < 1 || value > 4) return fail(LBM_ERR_ARG, "fuse must be 1, 2, 3 or 4 (4: tile kernel, no strip faces)"); c->fuse = (int)value; c->deep = 0; }
     else if (k == "deep") {     // k_stepd_tile: 1: 6 iterations on 64x16 tiles, 2: 7 on 64x16, 3: 8 on 32x32 (1024 threads);
-                                // k_stepc_col (registers): 6 / 7 / 9: 5 / 6 / 7 iterations on 64x32 regions; 8 (fp32): 7 iterations on 64x64 regions.
+                                // k_stepc_col (registers): 6 / 7 / 9: 5 / 6 / 7 iterations on 64x32 regions; 8 (fp32): 7 iterations on 64x48 regions.
         if (!deep_valid((int)value)) return fail(LBM_ERR_ARG, "deep must be 0..3 or 6..9 (4 / 5, round 2's 32x16 LDS tiles, are retired)");
-        if (deep_is_tall((int)value) && c->esize != 4) return fail(LBM_ERR_ARG, "deep 8 (64x64 regions in registers) exists in fp32 only: nine fp64 populations x eight rows do not fit the register file");
+        if (deep_is_tall((int)value) && c->esize != 4) return fail(LBM_ERR_ARG, "deep 8 (64x48 regions in registers, twelve waves x four rows) exists in fp32 only");
         c->deep = (int)value;
         if (c->deep) c->fuse = deep_depth(c->deep);
     }

@@ -72,7 +72,7 @@ void launch_rows(const lbm_ctx* c, const KArgs<T>& a, hipStream_t s) {
 // (k_stepc_col, R = 4 rows per thread x 8 waves = a 64 x 32 region per block, two blocks per CU; fp64 strict: 2 rows x 12 waves = 64 x 24) with five / six iterations —
 // a plan of either uses both depths, and on a context without strip faces seven iterations too, for what a segment leaves
 // over (20 = 7 + 7 + 6; at 4096x1024 fp64 seven iterations run at 160.6 GLUPS against 161.7 for six — eight, 154.3, are
-// not built); 9: the same family with seven iterations as the plan's depth (8192x2048 fp64: 175.9 against 169.9); 8: fp32 only, the same kernel on TALL 64 x 64 regions (eight rows per thread) with seven iterations, six / eight for
+// not built); 9: the same family with seven iterations as the plan's depth (8192x2048 fp64: 175.9 against 169.9); 8: fp32 only, the same kernel on TALL 64 x 48 regions (twelve waves x four rows) with seven iterations, six / eight for
 // what a segment leaves over. Ids 4 / 5 were round 2's 32x16 LDS tiles: retired.
 // rows of one band of tiles of a launch of `depth` iterations (the edge bands of a strip are one band each)
 inline int deep_rows(const lbm_ctx* c, int id, int depth) {

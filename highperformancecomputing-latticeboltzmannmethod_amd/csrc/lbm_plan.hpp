@@ -16,7 +16,7 @@ namespace lbmk {
 // ty: tile height of the two- / three-iteration tile kernels (8 or 12); xcd: XCD-aware tile walk; deep: 0, or the deep shape
 // (1..3: k_stepd_tile six / seven / eight iterations; 6 / 7: k_stepc_col five / six iterations in registers on 64x32 regions;
 // 9: the same kernel with SEVEN iterations as the plan's depth — the largest grids; 8: fp32 only, k_stepc_col seven iterations
-// on TALL 64x64 regions — lbm_col_api.hpp); ntl: the register kernel's level-1 loads
+// on TALL 64x48 regions — lbm_col_api.hpp); ntl: the register kernel's level-1 loads
 // are non-temporal
 struct Plan { int layout, variant, nt, alternate, fuse, ty, xcd; std::string name; int deep = 0; int ntl = 0; };
 
@@ -100,10 +100,10 @@ inline std::vector<Plan> plan_candidates(const PlanQuery& q, const Plan& fixed) 
         cand.push_back({1, 1, 0, 0, 7, 12, 1, "row-interleaved/7-step 64x32 in registers/xcd", 9});
         cand.push_back({1, 1, 0, 1, 7, 12, 1, "row-interleaved/7-step 64x32 in registers/alternate/xcd", 9});
     }
-    // (round 4, fp32: 64x64 regions — 16384x4096 311 GLUPS against 289-292 on 64x32; loses on three rounds of blocks, 4096x1024)
+    // (round 4, fp32: 64x48 regions on twelve waves — 16384x4096 320 GLUPS against 289-298 on 64x32; 4096x1024 262 against 260)
     if (q.esize == 4 && !small_grid) {
-        cand.push_back({1, 1, 0, 0, 7, 12, 1, "row-interleaved/7-step 64x64 in registers/xcd", 8});
-        cand.push_back({1, 1, 0, 1, 7, 12, 1, "row-interleaved/7-step 64x64 in registers/alternate/xcd", 8});
+        cand.push_back({1, 1, 0, 0, 7, 12, 1, "row-interleaved/7-step 64x48 in registers/xcd", 8});
+        cand.push_back({1, 1, 0, 1, 7, 12, 1, "row-interleaved/7-step 64x48 in registers/alternate/xcd", 8});
     }
     cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x16/nt-store/xcd", 1});
     if (small_grid && !q.faces) {   // one round of LDS-filling tiles: a launch's load and store phases are paid once per 7-8 iterations

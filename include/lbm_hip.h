@@ -175,8 +175,8 @@ int  lbm_load_state(lbm_ctx* c, const char* path);
  *                 64x16 / 64x16 / 32x32 tile (k_stepd_tile, 1024-thread blocks: grids of a single round of blocks); 6 / 7:
  *                 five / six iterations with the lattice of a 64x32 region held in registers (k_stepc_col, 512-thread
  *                 blocks, two per CU: large grids; a plan of this family uses both depths to split a call without a slow
- *                 tail; 9: the same with seven iterations as the plan's depth: the largest grids); 8 (fp32 contexts only, LBM_ERR_ARG otherwise): seven iterations on a 64x64 region in registers
- *                 (eight rows per thread; six / eight iterations for what a call leaves over): the largest fp32 grids.
+ *                 tail; 9: the same with seven iterations as the plan's depth: the largest grids); 8 (fp32 contexts only, LBM_ERR_ARG otherwise): seven iterations on a 64x48 region in registers
+ *                 (twelve waves x four rows; six / eight iterations for what a call leaves over): large fp32 grids.
  *                 Strips use 1, 6, 7 by rule with one exchange per launch; 4 / 5 (round 2's 32x16 LDS tiles) are retired,
  *                 "arith" 0 strict IEEE collision (bit-identical to the CPU oracle for normal-range operands: lbm_debug_strict_div2) | 1 FMA-contracted (<= 1e-10)
  *   strips:       "overlap" 0 launch and exchange serialised | 1 edge bands first, the exchange overlapped with the interior

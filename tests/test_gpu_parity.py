@@ -71,7 +71,7 @@ PLANS = {
     "fast-rowil-col7": dict(tune=0, layout=1, variant=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=9, arith=1),
 }
 FAST = [k for k, v in PLANS.items() if v and v.get("arith")]
-# fp32 contexts only (round 4): seven iterations per launch on TALL 64x64 regions in registers (strict arithmetic: 64x48)
+# fp32 contexts only (round 4): seven iterations per launch on TALL 64x48 regions in registers (contracted: twelve waves x four rows; strict: eight x six)
 TALL_F32 = dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair_ty=12, xcd=1, deep=8)
 
 

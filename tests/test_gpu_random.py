@@ -188,7 +188,7 @@ def fp32_cases(n=24, seed=20261004):
 
 @pytest.mark.parametrize("case", fp32_cases(), ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}" + ("-fast" if c[10]["arith"] else "") + (f"-{c[11]}strips" if c[11] > 1 else ""))
 def test_random_fp32_tall_regions_match_one_launch_per_iteration(case):
-    """fp32 has no oracle (the reference is fp64): the tall register shape ("deep" 8: 64x64 regions, strict arithmetic 64x48; seven
+    """fp32 has no oracle (the reference is fp64): the tall register shape ("deep" 8: 64x48 regions — twelve waves x four rows, strict arithmetic eight x six; seven
     iterations per launch, six / eight for remainders) is held bit for bit to one k_step_site launch per iteration in the same
     arithmetic on random ragged grids — whole domains and groups of strips; the fp32 path itself is held to the fp64 oracle at a
     stated tolerance in tests/test_gpu_parity.py."""

@@ -281,14 +281,14 @@ def test_seven_and_eight_iteration_lds_shapes_on_strips(lbm, deep, precision):
 
 @pytest.mark.parametrize("arith", [0, 1])
 def test_tall_fp32_regions_in_registers(lbm, arith):
-    """Round 4, fp32 only ("deep" 8): k_stepc_col on 64x64 regions (eight rows per thread; strict arithmetic: six, 64x48) with
+    """Round 4, fp32 only ("deep" 8): k_stepc_col on 64x48 regions (contracted arithmetic: twelve waves x four rows; strict: eight x six) with
     seven iterations per launch and six / eight for what a segment leaves over — the measured plan of 16384x4096 fp32. Same
     per-cell operation sequence as one launch per iteration: bit-identical populations and forces on ragged grids with every
     boundary and the cylinder (on the inlet column too), as a whole domain, as groups of even / uneven strips (seven rows per
     exchange), over the one-rank RCCL transport, eager and replayed from a graph. fp64 contexts refuse the shape."""
     with pytest.raises(lbm.LbmError, match="fp32 only"):
         lbm.Context(256, 64, precision="f64", options=dict(tune=0, deep=8))
-    rows = 8 if arith else 6
+    shape = "4,12" if arith else "6,8"      # rows per thread, waves per block
     site = dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1, arith=arith)
     tall = dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair_ty=12, xcd=1, deep=8, arith=arith)
     for (nx, ny, steps, of, kw) in ((300, 170, 333, 45, dict(inlet_velocity=0.05, cylinder_radius=0.1)),
@@ -302,7 +302,7 @@ def test_tall_fp32_regions_in_registers(lbm, arith):
         for extra in (dict(), dict(trailing_pair=1), dict(layout=0, alternate=0)):
             with lbm.Context(nx, ny, options=dict(tall, timing=1, **extra), **kw) as ctx:
                 ctx.initialise()
-                assert f"k_stepc_col<float,{rows},8,7,false,{arith}>" == ctx.kernel_name().replace(" ", ""), ctx.kernel_name()
+                assert f"k_stepc_col<float,{shape},7,false,{arith}>" == ctx.kernel_name().replace(" ", ""), ctx.kernel_name()
                 ctx.step(steps, of)
                 if extra.get("trailing_pair"):
                     ctx.step(1, 0)
@@ -322,7 +322,7 @@ def test_tall_fp32_regions_in_registers(lbm, arith):
             for extra in (dict(), dict(overlap=0, group_threads=0)):
                 with lbm.Group(nx, ny, bounds, options=dict(tall, **extra), **kw) as g:
                     g.initialise()
-                    assert all(f"<float,{rows},8,7," in m.kernel_name().replace(" ", "") for m in g.ctxs), g.ctxs[0].kernel_name()
+                    assert all(f"<float,{shape},7," in m.kernel_name().replace(" ", "") for m in g.ctxs), g.ctxs[0].kernel_name()
                     g.step(steps, of)
                     assert g.first_unstable_step() == -1
                     assert np.array_equal(g.populations("f_next"), w_fn), (nx, ny, bounds, extra)

@@ -232,6 +232,13 @@ std::vector<Variant<T>> variants() {
         v.push_back(col_variant<T, 8, 8, 7, AR>(false, true));
         v.push_back(col_variant<T, 8, 8, 8, AR>(false, true));
         v.push_back(col_variant<T, 8, 8, 8, AR>(true, true));
+        // (trimmed exchange buffer: more waves per block at the standard register budget)
+        v.push_back(col_variant<T, 4, 12, 6, AR>(false, true));
+        v.push_back(col_variant<T, 4, 12, 7, AR>(false, true));
+        v.push_back(col_variant<T, 4, 12, 6, AR>(true, false));
+        v.push_back(col_variant<T, 3, 16, 6, AR>(false, true));
+        v.push_back(col_variant<T, 3, 16, 7, AR>(false, true));
+        v.push_back(col_variant<T, 2, 16, 6, AR>(false, true));
     }
     v.push_back(pipe_variant<T, 4, 8, 6, AR>(2));
     v.push_back(pipe_variant<T, 4, 8, 6, AR>(3));
