@@ -120,9 +120,15 @@ def _same(a, b):
 
 
 def kernel_family(kernel):
-    """('k_stepc_col', 'double', depth) etc.: what a sibling entry (other store policy / arithmetic flag) must share."""
-    m = re.match(r"(k_step\w*)<(\w+)", kernel.replace(" ", ""))
-    return (m.group(1), m.group(2), plan_depth_of(kernel)) if m else (kernel, "", 0)
+    """('k_stepc_col', 'double', depth[, rows per thread, waves]) etc.: what a sibling entry may NOT differ in — only the store
+    policy and the arithmetic flag may (the tall 64x48 fp32 regions <float,4,12,7,..> and the 64x32 ones <float,4,8,7,..>
+    fetch 1.35 x against 1.59 x the lattice and used to count as siblings)."""
+    k = kernel.replace(" ", "")
+    m = re.match(r"(k_step\w*)<(\w+)", k)
+    if not m:
+        return (kernel, "", 0)
+    shape = re.match(r"k_stepc_col<\w+,(\d+),(\d+),", k)
+    return (m.group(1), m.group(2), plan_depth_of(k)) + ((int(shape.group(1)), int(shape.group(2))) if shape else ())
 
 
 def measured_traffic(nx, local_ny, precision, kernel, layout="", build_id=None):
@@ -181,6 +187,12 @@ def live_counters(nx, ny, precision, arith, plan_options, steps, re_number=200.0
     base = keep_dir or tempfile.mkdtemp(prefix="lbm_pmc_")
     tot, disp, kernels, probe = {}, {}, {}, None
     env = dict(os.environ, TMPDIR="/tmp")
+
+    def give_up(why):      # every failure: the scratch directory goes, and no later call of this run repeats the passes
+        _LIVE_BROKEN.append(why)
+        if not keep_dir:
+            shutil.rmtree(base, ignore_errors=True)
+        return None, why
     for gi, group in enumerate(PMC_GROUPS):
         d = os.path.join(base, f"pass{gi}_{group[0].lower()}")
         cmd = [rocprof, "--pmc", *group, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
@@ -190,16 +202,14 @@ def live_counters(nx, ny, precision, arith, plan_options, steps, re_number=200.0
             out = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                  start_new_session=True)
         except subprocess.TimeoutExpired:
-            _LIVE_BROKEN.append(f"counter pass {group[0]} timed out after {timeout} s")
-            return None, _LIVE_BROKEN[0]
+            return give_up(f"counter pass {group[0]} timed out after {timeout} s")
         m = re.search(r'^\{"probe".*$', out.stdout, re.M)
         if out.returncode != 0 or not m:
-            _LIVE_BROKEN.append(f"counter pass {group[0]} failed (rc {out.returncode}): {(out.stderr or out.stdout)[-200:]}")
-            return None, _LIVE_BROKEN[0]
+            return give_up(f"counter pass {group[0]} failed (rc {out.returncode}): {(out.stderr or out.stdout)[-200:]}")
         probe = json.loads(m.group(0))
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if not files:
-            return None, f"counter pass {group[0]} wrote no counter_collection.csv"
+            return give_up(f"counter pass {group[0]} wrote no counter_collection.csv")
         for f in files:
             with open(f, newline="") as fh:
                 for r in csv.DictReader(fh):
@@ -214,10 +224,10 @@ def live_counters(nx, ny, precision, arith, plan_options, steps, re_number=200.0
     if not keep_dir:
         shutil.rmtree(base, ignore_errors=True)
     if "FETCH_SIZE" not in tot or "WRITE_SIZE" not in tot or not probe:
-        return None, "counter passes returned no FETCH_SIZE / WRITE_SIZE rows for the step kernels"
+        return give_up("counter passes returned no FETCH_SIZE / WRITE_SIZE rows for the step kernels")
     launches = probe["launches"]
     if disp["FETCH_SIZE"] != launches or disp["WRITE_SIZE"] != launches:
-        return None, f"dispatch count mismatch: probe issued {launches} step launches, passes saw {disp['FETCH_SIZE']} / {disp['WRITE_SIZE']}"
+        return give_up(f"dispatch count mismatch: probe issued {launches} step launches, passes saw {disp['FETCH_SIZE']} / {disp['WRITE_SIZE']}")
     fetch = tot["FETCH_SIZE"] * 1024 * 2 / launches      # KiB -> B; x2: gfx950 tallies the 128-B requests of a coalesced read stream at 64 B
     write = tot["WRITE_SIZE"] * 1024 / launches
     e = {"kernel": probe["kernel"], "hbm_bytes_per_launch": int(fetch + write), "fetch_bytes_corrected": int(fetch), "write_bytes": int(write),

@@ -30,69 +30,182 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
 
+// A stall must name itself (a GPU tool sat silent for seven minutes and was killed with nothing on record): with
+// LBM_TRACE=<file> in the environment the library appends one line per coarse event (create / comm_init / initialise / step /
+// group_step / destroy, begin and end) with a timestamp, pid and thread, flushed at once. Off: one cached getenv.
+inline void lbm_trace(const char* what, const char* fmt = nullptr, ...) {
+    static FILE* fp = [] { const char* f = getenv("LBM_TRACE"); return (f && *f) ? fopen(f, "a") : (FILE*)nullptr; }();
+    if (!fp) return;
+    static std::mutex mu;
+    const double t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    char detail[256] = "";
+    if (fmt) { va_list ap; va_start(ap, fmt); vsnprintf(detail, sizeof(detail), fmt, ap); va_end(ap); }
+    std::lock_guard<std::mutex> lk(mu);
+    fprintf(fp, "%.6f pid %d tid %lx %s %s\n", t, (int)getpid(), (unsigned long)std::hash<std::thread::id>{}(std::this_thread::get_id()) & 0xffffff, what, detail);
+    fflush(fp);
+}
+// the bound of every host-side wait of the library (rendezvous of a group's threads, completion of a group job, lbm_sync,
+// the drains of lbm_destroy): LBM_WAIT_TIMEOUT_MS, default five minutes — below the seven minutes of silence after which the
+// GPU harness kills a command, far above anything a healthy run waits for (a full hardware queue drains in seconds)
+inline long default_wait_timeout_ms() {
+    static const long v = [] { const char* e = getenv("LBM_WAIT_TIMEOUT_MS"); const long x = e ? atol(e) : 0; return x > 0 ? x : 300000L; }();
+    return v;
+}
+
 // The host threads of an in-process group of strips (lbm_group_link): one per strip beyond the first, created ONCE and parked
 // on a condition variable between lbm_group_step calls (a call used to spawn and join n-1 std::threads: Solver::run issues one
 // call per output chunk, ~1 ms of GPU work at N = 8). Strip 0 is driven by the calling thread. Inside a job the n threads move
-// in lockstep through `sync`; whether a phase aborts is decided ONCE per rendezvous, in the barrier's completion step, from
-// the error state as it stood when the last thread arrived — so every thread takes the same branch and nobody is left
-// waiting at the next rendezvous (a thread that failed after a rendezvous used to make a slower one return early).
+// in lockstep through `arrive`; whether a phase aborts is decided ONCE per rendezvous, by the last thread to arrive, from
+// the error state as it stood then — so every thread takes the same branch and nobody is left waiting at the next rendezvous
+// (a thread that failed after a rendezvous used to make a slower one return early).
+// EVERY WAIT IS BOUNDED (round 5; rounds 3-4 used std::barrier and an untimed condition variable): a rendezvous that is not
+// complete after `timeout_ms`, or a job whose threads have not all returned by then, turns into LBM_ERR_TIMEOUT with the strips
+// that are missing and the launch / rendezvous each was last seen at, and poisons the pool: later jobs are refused, and the
+// contexts of a poisoned group whose threads never came back are leaked by lbm_destroy rather than freed under a thread that
+// may still wake up (the state the threads share lives on the heap and outlives the pool; a job's own state lives in its closure).
 struct GroupPool {
-    struct Snap {
-        GroupPool* p;
-        void operator()() noexcept { p->phase_err = p->err.load(); }
+    struct State {
+        const int n;
+        std::mutex mu;
+        std::condition_variable cv_job, cv_done, cv_bar;
+        std::function<void(State&, int)> job;      // a COPY of the caller's closure (which owns its state through a shared_ptr)
+        unsigned long gen = 0;
+        int pending = 0;
+        bool stop = false;
+        long timeout_ms = default_wait_timeout_ms();
+        // rendezvous: arrivals are counted lock-free and a waiter spins for a few microseconds before it blocks (a launch of an
+        // N = 8 strip is ~20 us of GPU work and passes three rendezvous)
+        std::atomic<int> arrived{0};
+        std::atomic<unsigned long> bgen{0};
+        std::atomic<bool> broken{false};
+        std::vector<std::atomic<int>> at;          // per strip: 4 * launch + rendezvous it last arrived at (for the message)
+        std::atomic<int> err{0};
+        int phase_err = 0;                 // written by the last arrival of a rendezvous only: the same for every thread of a phase
+        std::mutex emu;
+        std::string msg;
+        explicit State(int n_) : n(n_), at((size_t)n_) { for (auto& a : at) a.store(-1); }
+        void report(int rc, const char* text) {
+            if (rc == 0) return;
+            std::lock_guard<std::mutex> lk(emu);
+            if (err.load() == 0) { msg = text; err.store(rc); }
+        }
+        std::string missing(int mine) {    // who has not arrived where strip `mine` waits
+            std::string s;
+            for (int k = 0; k < n; ++k) {
+                const int a = at[(size_t)k].load();
+                if (a >= mine) continue;
+                char b[96];
+                if (a < 0) snprintf(b, sizeof(b), "%sstrip %d (not yet at any rendezvous of this call)", s.empty() ? "" : ", ", k);
+                else snprintf(b, sizeof(b), "%sstrip %d (last seen at rendezvous %d of launch %d)", s.empty() ? "" : ", ", k, a % 4, a / 4);
+                s += b;
+            }
+            return s.empty() ? std::string("nobody (a late arrival)") : s;
+        }
+        // rendezvous `phase` (1..3) of launch `launch` of this call; true: some strip had failed by the time the last one arrived,
+        // or the rendezvous timed out — EVERY thread sees true and leaves
+        bool arrive(int i, int launch, int phase) {
+            const int mine = 4 * launch + phase;
+            at[(size_t)i].store(mine);
+            if (broken.load()) return true;
+            const unsigned long g = bgen.load(std::memory_order_acquire);
+            if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+                arrived.store(0, std::memory_order_relaxed);
+                phase_err = err.load();
+                { std::lock_guard<std::mutex> lk(mu); bgen.store(g + 1, std::memory_order_release); }
+                cv_bar.notify_all();
+                return phase_err != 0 || broken.load();
+            }
+            for (int k = 0; k < 4000; ++k) {
+                if (bgen.load(std::memory_order_acquire) != g) return phase_err != 0 || broken.load();
+                __builtin_ia32_pause();
+            }
+            std::unique_lock<std::mutex> lk(mu);
+            if (!cv_bar.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return bgen.load(std::memory_order_acquire) != g || broken.load(); })) {
+                broken.store(true);
+                char b[512];
+                snprintf(b, sizeof(b), "strip %d waited %ld ms at rendezvous %d of launch %d of this call for: %s; the group is unusable, destroy it",
+                         i, timeout_ms, phase, launch, missing(mine).c_str());
+                report(LBM_ERR_TIMEOUT, b);
+                lbm_trace("TIMEOUT", "%s", b);
+                cv_bar.notify_all();
+                return true;
+            }
+            return phase_err != 0 || broken.load();
+        }
     };
-    const int n;
+    std::shared_ptr<State> S;
     std::vector<std::thread> th;
-    std::mutex mu;
-    std::condition_variable cv_job, cv_done;
-    const std::function<void(int)>* job = nullptr;
-    unsigned long gen = 0;
-    int pending = 0;
-    bool stop = false;
-    std::atomic<int> err{0};
-    int phase_err = 0;                 // written by the barrier's completion step only: the same for every thread of a phase
-    std::mutex emu;
-    std::string msg;
-    std::barrier<Snap> sync;
-    explicit GroupPool(int n_) : n(n_), sync(n_, Snap{this}) {
-        for (int i = 1; i < n; ++i) th.emplace_back([this, i] { loop(i); });
+    explicit GroupPool(int n_) : S(std::make_shared<State>(n_)) {
+        for (int i = 1; i < n_; ++i) th.emplace_back([s = S, i] { loop(*s, i); });
+    }
+    // all threads parked? (a poisoned pool: waits up to `grace_ms` for the stragglers first)
+    bool quiesce(long grace_ms) {
+        std::unique_lock<std::mutex> lk(S->mu);
+        return S->cv_done.wait_for(lk, std::chrono::milliseconds(grace_ms), [&] { return S->pending == 0; });
     }
     ~GroupPool() {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cv_job.notify_all();
-        for (auto& t : th) t.join();
+        const bool idle = quiesce(S->broken.load() ? std::max(5000L, S->timeout_ms) : 0x7fffffffL);
+        { std::lock_guard<std::mutex> lk(S->mu); S->stop = true; S->job = nullptr; }
+        S->cv_job.notify_all();
+        for (auto& t : th) { if (idle) t.join(); else t.detach(); }      // (a thread that never came back keeps the shared state alive)
     }
-    void loop(int i) {
+    static void loop(State& s, int i) {
         unsigned long seen = 0;
         for (;;) {
-            const std::function<void(int)>* f;
+            std::function<void(State&, int)> f;
             {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_job.wait(lk, [&] { return stop || gen != seen; });
-                if (stop) return;
-                seen = gen; f = job;
+                std::unique_lock<std::mutex> lk(s.mu);
+                s.cv_job.wait(lk, [&] { return s.stop || s.gen != seen; });      // (parked: the one wait without a bound, ended by ~GroupPool)
+                if (s.stop) return;
+                seen = s.gen; f = s.job;
             }
-            (*f)(i);
-            { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv_done.notify_one(); }
+            f(s, i);
+            s.at[(size_t)i].store(INT_MAX);
+            { std::lock_guard<std::mutex> lk(s.mu); if (--s.pending == 0) s.cv_done.notify_all(); }
         }
     }
-    // run f(0) .. f(n-1), one strip per thread; returns when all are done
-    void run(const std::function<void(int)>& f) {
-        err.store(0); phase_err = 0; msg.clear();
-        { std::lock_guard<std::mutex> lk(mu); job = &f; pending = n - 1; ++gen; }
-        cv_job.notify_all();
-        f(0);
-        std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [&] { return pending == 0; });
+    // run f(S, 0) .. f(S, n-1), one strip per thread; returns when all are done — or LBM_ERR_TIMEOUT after timeout_ms
+    int run(std::function<void(State&, int)> f, long timeout_ms) {
+        State& s = *S;
+        if (s.broken.load()) return fail(LBM_ERR_TIMEOUT, "this group timed out earlier (%s): destroy it", s.msg.c_str());
+        s.err.store(0); s.phase_err = 0; s.msg.clear(); s.arrived.store(0);
+        for (auto& a : s.at) a.store(-1);
+        { std::lock_guard<std::mutex> lk(s.mu); s.timeout_ms = timeout_ms > 0 ? timeout_ms : default_wait_timeout_ms(); s.job = f; s.pending = s.n - 1; ++s.gen; }
+        s.cv_job.notify_all();
+        f(s, 0);
+        s.at[0].store(INT_MAX);
+        std::unique_lock<std::mutex> lk(s.mu);
+        if (!s.cv_done.wait_for(lk, std::chrono::milliseconds(s.timeout_ms), [&] { return s.pending == 0; })) {
+            s.broken.store(true);
+            char b[512];
+            snprintf(b, sizeof(b), "%d strip thread(s) have not come back %ld ms after strip 0 finished its part: %s; the group is unusable, destroy it",
+                     s.pending, s.timeout_ms, s.missing(INT_MAX).c_str());
+            s.report(LBM_ERR_TIMEOUT, b);
+            lbm_trace("TIMEOUT", "%s", b);
+            s.cv_bar.notify_all();
+        } else s.job = nullptr;
+        if (s.err.load() != LBM_OK) return fail(s.err.load(), "%s", s.msg.c_str());
+        return LBM_OK;
     }
-    void report(int rc, const char* text) {
-        if (rc == 0) return;
-        std::lock_guard<std::mutex> lk(emu);
-        if (err.load() == 0) { msg = text; err.store(rc); }
-    }
-    // rendezvous; true: some strip had failed by the time the last one arrived — EVERY thread sees true and leaves
-    bool arrive() { sync.arrive_and_wait(); return phase_err != 0; }
 };
+
+// Dry run of the strip choreography (lbm_debug_choreography, include/lbm_hip.h; no device needed). With `rec` set on a context the
+// functions that issue a launch group — plan_launch, issue_before, the exchanges, issue_after, join_comm, the force launch — append
+// what they WOULD queue instead of calling the runtime: kernels with the rows they write (and, through their depth, read), event
+// records, cross-stream waits, copies, sends and receives, each with its stream. lbm_choreo.inc.hpp replays the list with vector
+// clocks and reports every pair of conflicting accesses that no event orders, and every launch that reads a row of the wrong
+// iteration: the class of round 4's edge-band race (a band shorter than the rows that travel), found then by a 1-in-15 flake.
+struct ChoreoOp {
+    enum { KERNEL = 0, RECORD = 1, WAIT = 2, COPY = 3, SEND = 4, RECV = 5, FORCES = 6 };
+    int kind = 0;
+    int strip = 0, stream = 0;      // the issuing strip, 0 main / 1 side stream
+    int ev_strip = 0, ev = 0;       // RECORD / WAIT: the event's owner and 0 ev_main, 1 ev_edge, 2 ev_comm
+    int buf = 0;                    // KERNEL: the buffer written (it reads buf ^ 1); COPY / SEND / RECV / FORCES: the buffer touched
+    int t = 0, depth = 0;           // KERNEL: first iteration and iterations; FORCES: the iteration
+    int w0[2] = {0, 0}, w1[2] = {0, 0};   // rows written, [w0, w1) in local rows (ghost rows: < 0 or >= nyl); KERNEL: two ranges
+    int r0 = 0, r1 = 0, r_strip = -1;     // COPY / SEND / FORCES: rows read and whose (RECV: where the data comes from; -1: another process)
+};
+struct Choreo { std::vector<ChoreoOp> ops; };
 
 struct lbm_ctx {
     lbm_params p{};
@@ -123,7 +236,6 @@ struct lbm_ctx {
     double feq_in[Q];
     int cyl_x = 0, cyl_y = 0, cyl_r = 0;
     // options
-    int variant = 0;     // (unused since round 4: it chose the retired k_step_vec; the option is accepted so that old plan strings still load)
     int alternate = 1;   // walk the rows bottom-up / top-down on alternate steps (Infinity Cache reuse)
     int use_nt = 0;      // non-temporal stores in the step kernel
     int use_ntl = 0;     // non-temporal level-1 loads in the register kernel (k_stepc_col)
@@ -167,6 +279,12 @@ struct lbm_ctx {
     lbm_ctx* nb_north = nullptr;
     int group_transport = 0, group_n = 1, group_k = 0;
     int group_threads = 1;   // a group is driven by one host thread per strip (0: the calling thread issues for every strip)
+    long wait_timeout_ms = 0;    // bound of the host-side waits (0: LBM_WAIT_TIMEOUT_MS or five minutes); option "wait_timeout_ms"
+    // TEST ONLY (options "debug_fault_launch" / "_point" / "_stall_ms"): in launch `launch` of the next lbm_group_step call this strip
+    // fails (stall_ms 0: an injected LBM_ERR_HIP) or sleeps, at point 0 (before the first rendezvous), 1 or 2 (between rendezvous)
+    int debug_fault_launch = -1, debug_fault_point = 0, debug_fault_stall_ms = 0;
+    Choreo* rec = nullptr;        // dry run (lbm_debug_choreography): record what would be queued, call no runtime function
+    int debug_old_edge_band = 0;  // TEST ONLY: the edge-band height as it was before round 4's fix (the detector must flag it)
     bool owns_comm = true;
     std::shared_ptr<GroupPool> pool;   // the group's host threads (shared by its members)
     int edge_rows[2] = {0, 0};   // edge-band heights of the launch in flight (issue_before -> issue_after)
@@ -185,4 +303,27 @@ struct lbm_ctx {
     // host-staged halo staging (device side)
     double* d_halo = nullptr;  // 4 faces-in-flight x [HR1][9][nx] doubles
 };
+
+// hipStreamSynchronize with a bound: polls hipStreamQuery (busy for the first 200 us — the end of a timed window must not pay a
+// scheduler quantum — then yielding, then sleeping 100 us at a time) and gives up with LBM_ERR_TIMEOUT after the context's
+// "wait_timeout_ms" (LBM_WAIT_TIMEOUT_MS, five minutes), saying which stream of which strip was still busy at which iteration.
+inline int wait_stream(const lbm_ctx* c, hipStream_t s, const char* what) {
+    const long limit_ms = c->wait_timeout_ms > 0 ? c->wait_timeout_ms : default_wait_timeout_ms();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return LBM_OK;
+        if (e != hipErrorNotReady) return fail(LBM_ERR_HIP, "hipStreamQuery(%s) -> %s", what, hipGetErrorString(e));
+        (void)hipGetLastError();
+        const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (us > limit_ms * 1000L) {
+            const int rc = fail(LBM_ERR_TIMEOUT, "%s of the strip of rows %d..%d on device %d still busy after %ld ms (work queued up to iteration %d)",
+                                what, c->p.y_start, c->p.y_start + c->nyl, c->device, limit_ms, c->steps_done);
+            lbm_trace("TIMEOUT", "%s", g_err);
+            return rc;
+        }
+        if (us > 5000) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        else if (us > 200) std::this_thread::yield();
+    }
+}
 

@@ -8,13 +8,14 @@
 #include <rccl/rccl.h>
 
 #include <climits>
+#include <cstdint>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
-#include <barrier>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -23,6 +24,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 using namespace lbmk;
 
@@ -33,6 +36,7 @@ namespace {
 #include "lbm_strips.inc.hpp"
 #include "lbm_tune.inc.hpp"
 #include "lbm_steps.inc.hpp"
+#include "lbm_choreo.inc.hpp"
 }  // namespace
 
 namespace {
@@ -195,23 +199,34 @@ int lbm_create(const lbm_params* p, int device, lbm_ctx** out) {
 
 void lbm_destroy(lbm_ctx* c) {
     if (!c) return;
+    lbm_trace("destroy", "ctx %p begin", (void*)c);
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
-    // (a graph that captured RCCL operations holds the communicator: ncclCommDestroy waits for it to go away first)
-    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
-    if (c->comm) ncclCommDestroy(c->comm);
+    // A group that ran into LBM_ERR_TIMEOUT: its threads may still be inside a runtime call on this context's streams. Wait for them
+    // (bounded); if they never come back, or the streams never drain, the context is LEAKED — freeing it under a thread that may still
+    // wake up, or blocking for ever in a drain, would turn a reported error into a crash or a hang.
+    bool leak = c->pool && c->pool->S->broken.load() && !c->pool->quiesce(std::max(5000L, c->pool->S->timeout_ms));
+    if (!leak && c->stream && wait_stream(c, c->stream, "compute stream (lbm_destroy)") == LBM_ERR_TIMEOUT) leak = true;
+    if (!leak && c->comm_stream && wait_stream(c, c->comm_stream, "exchange stream (lbm_destroy)") == LBM_ERR_TIMEOUT) leak = true;
     for (lbm_ctx* nb : {c->nb_south, c->nb_north}) {  // a destroyed member leaves its group
         if (!nb) continue;
         // the neighbour's exchange stream may still hold a pull (hipMemcpyPeerAsync) that READS this member's edge rows, and
         // freeing a buffer only waits for work of this member's own device: drain the neighbour's streams first
         (void)hipSetDevice(nb->device);
-        if (nb->comm_stream) (void)hipStreamSynchronize(nb->comm_stream);
-        if (nb->stream) (void)hipStreamSynchronize(nb->stream);
+        if (!leak && nb->comm_stream && wait_stream(nb, nb->comm_stream, "a neighbour's exchange stream (lbm_destroy)") == LBM_ERR_TIMEOUT) leak = true;
+        if (!leak && nb->stream && wait_stream(nb, nb->stream, "a neighbour's compute stream (lbm_destroy)") == LBM_ERR_TIMEOUT) leak = true;
         if (nb->nb_south == c) nb->nb_south = nullptr;
         if (nb->nb_north == c) nb->nb_north = nullptr;
     }
     (void)hipSetDevice(c->device);
+    if (leak) {
+        fprintf(stderr, "lbm_destroy: context %p left allocated (%s)\n", (void*)c, g_err);
+        lbm_trace("destroy", "ctx %p LEAKED: %s", (void*)c, g_err);
+        c->nb_south = c->nb_north = nullptr;
+        return;
+    }
+    // (a graph that captured RCCL operations holds the communicator: ncclCommDestroy waits for it to go away first)
+    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    if (c->comm) { lbm_trace("destroy", "ctx %p ncclCommDestroy", (void*)c); ncclCommDestroy(c->comm); }
     c->pool.reset();
     void* ptrs[] = {c->buf[0], c->buf[1], c->scratch, c->d_macro, c->d_maxbits, c->d_unstable, c->d_tbase, c->d_solid_count, c->d_feq,
                     c->d_force_now, c->d_force_log, c->d_halo, c->d_red};
@@ -222,14 +237,16 @@ void lbm_destroy(lbm_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    lbm_trace("destroy", "ctx %p end", (void*)c);
     delete c;
 }
 
 int lbm_initialise(lbm_ctx* c, int* solid_count_out) {
     if (!c) return fail(LBM_ERR_ARG, "null context");
+    lbm_trace("initialise", "ctx %p %dx%d rows %d..%d begin", (void*)c, c->nx, c->p.ny, c->p.y_start, c->p.y_start + c->nyl);
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));        // (re-)initialisation starts from quiet streams
-    HIPCHK(hipStreamSynchronize(c->comm_stream));
+    { int wr = wait_stream(c, c->stream, "compute stream (lbm_initialise)"); if (wr) return wr; }        // (re-)initialisation starts from quiet streams
+    { int wr = wait_stream(c, c->comm_stream, "exchange stream (lbm_initialise)"); if (wr) return wr; }
     c->steps_done = 0;
     c->log_count = 0;
     c->mid_pair = false;
@@ -246,6 +263,7 @@ int lbm_initialise(lbm_ctx* c, int* solid_count_out) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (solid_count_out) *solid_count_out = sc;
     c->initialised = true;
+    lbm_trace("initialise", "ctx %p end: %s", (void*)c, c->plan_desc);
     return LBM_OK;
 }
 
@@ -254,15 +272,18 @@ int lbm_step(lbm_ctx* c, int nsteps, int output_frequency) {
     if (nsteps < 0) return fail(LBM_ERR_ARG, "nsteps < 0");
     if (c->group_n > 1) return fail(LBM_ERR_ARG, "this context is a member of a group: use lbm_group_step");
     HIPCHK(hipSetDevice(c->device));
-    return DISPATCH(c, do_steps<double>(&c, 1, nsteps, output_frequency), do_steps<float>(&c, 1, nsteps, output_frequency));
+    lbm_trace("step", "ctx %p t=%d +%d begin", (void*)c, c->steps_done, nsteps);
+    const int rc = DISPATCH(c, do_steps<double>(&c, 1, nsteps, output_frequency), do_steps<float>(&c, 1, nsteps, output_frequency));
+    lbm_trace("step", "ctx %p t=%d issued rc=%d", (void*)c, c->steps_done, rc);
+    return rc;
 }
 
 int lbm_sync(lbm_ctx* c) {
     if (!c) return fail(LBM_ERR_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipStreamSynchronize(c->comm_stream));
-    return LBM_OK;
+    int rc = wait_stream(c, c->stream, "compute stream");
+    if (!rc) rc = wait_stream(c, c->comm_stream, "exchange stream");
+    return rc;
 }
 
 int lbm_steps_done(const lbm_ctx* c) { return c ? c->steps_done : -1; }
@@ -385,7 +406,9 @@ int lbm_comm_init(lbm_ctx* c, int rank, int nranks, const void* id128) {
     HIPCHK(hipSetDevice(c->device));
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
+    lbm_trace("comm_init", "ctx %p rank %d of %d begin", (void*)c, rank, nranks);
     NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
+    lbm_trace("comm_init", "ctx %p end", (void*)c);
     c->rank = rank;
     c->nranks = nranks;
     if (nranks > 1 && c->nyl < 2 * HR1) return fail(LBM_ERR_ARG, "a strip with neighbours needs at least %d rows", 2 * HR1);
@@ -513,7 +536,10 @@ int lbm_group_step(lbm_ctx** cs, int n, int nsteps, int output_frequency) {
     if (nsteps < 0) return fail(LBM_ERR_ARG, "nsteps < 0");
     for (int k = 0; k < n; ++k)
         if (!cs[k]->initialised) return fail(LBM_ERR_ARG, "context not initialised");
-    return DISPATCH(cs[0], do_steps<double>(cs, n, nsteps, output_frequency), do_steps<float>(cs, n, nsteps, output_frequency));
+    lbm_trace("group_step", "%d strips t=%d +%d begin", n, cs[0]->steps_done, nsteps);
+    rc = DISPATCH(cs[0], do_steps<double>(cs, n, nsteps, output_frequency), do_steps<float>(cs, n, nsteps, output_frequency));
+    lbm_trace("group_step", "%d strips t=%d issued rc=%d", n, cs[0]->steps_done, rc);
+    return rc;
 }
 
 int lbm_group_refresh_halos(lbm_ctx** cs, int n) {
@@ -589,10 +615,9 @@ int lbm_load_state(lbm_ctx* c, const char* path) {
 int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     if (!c || !key) return fail(LBM_ERR_ARG, "null argument");
     const std::string k(key);
-    if (c->initialised && (k == "variant" || k == "layout" || k == "nt" || k == "ntl" || k == "tune" || k == "pair" || k == "fuse" || k == "pair_ty" || k == "loopback" || k == "deep" || k == "arith"))
+    if (c->initialised && (k == "layout" || k == "nt" || k == "ntl" || k == "tune" || k == "pair" || k == "fuse" || k == "pair_ty" || k == "loopback" || k == "deep" || k == "arith"))
         return fail(LBM_ERR_ARG, "option %s must be set before lbm_initialise", key);
-    if (k == "variant") c->variant = (int)value;
-    else if (k == "timing") c->timing = (int)value;
+    if (k == "timing") c->timing = (int)value;
     else if (k == "alternate") c->alternate = (int)value;
     else if (k == "layout") c->layout = (int)value ? 1 : 0;
     else if (k == "nt") c->use_nt = (int)value ? 1 : 0;
@@ -612,6 +637,11 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "deep_halo") { if (value < 0 || value > 2) return fail(LBM_ERR_ARG, "deep_halo must be 0, 1 or 2"); c->deep_halo = (int)value; c->deep_pinned = true; }
     else if (k == "skip_exchange") c->skip_exchange = (int)value ? 1 : 0;
     else if (k == "group_threads") c->group_threads = (int)value ? 1 : 0;
+    else if (k == "wait_timeout_ms") { if (value < 0) return fail(LBM_ERR_ARG, "wait_timeout_ms must be >= 0 (0: LBM_WAIT_TIMEOUT_MS or five minutes)"); c->wait_timeout_ms = value; }
+    else if (k == "debug_fault_launch") c->debug_fault_launch = (int)value;      // TEST ONLY: see lbm_ctx
+    else if (k == "debug_fault_point") { if (value < 0 || value > 2) return fail(LBM_ERR_ARG, "debug_fault_point must be 0, 1 or 2"); c->debug_fault_point = (int)value; }
+    else if (k == "debug_fault_stall_ms") c->debug_fault_stall_ms = (int)value;
+    else if (k == "debug_old_edge_band") c->debug_old_edge_band = (int)value ? 1 : 0;      // TEST ONLY: see lbm_ctx
     else if (k == "graph") { if (value < 0 || value > 2) return fail(LBM_ERR_ARG, "graph must be 0, 1 or 2"); c->use_graph = (int)value; }
     else if (k == "loopback") c->loopback = (int)value;   // 0 off, 1 device copies, 2 RCCL self send/recv
     else if (k == "pair_ty") { if (value != 8 && value != 12) return fail(LBM_ERR_ARG, "pair_ty must be 8 or 12"); c->pair_ty = (int)value; }
@@ -652,7 +682,12 @@ long lbm_graph_replays(const lbm_ctx* c) { return c ? c->graph_replays : 0; }
 const char* lbm_kernel_name(const lbm_ctx* c) {
     if (!c) return "";
     static thread_local char name[96];
-    snprintf(name, sizeof(name), "%s", plan_kernel_name(c->fuse, c->deep, c->pair_ty, c->use_nt, c->arith, (int)c->esize).c_str());
+    // the kernel plan_launch really issues: a strip whose halos are staged through the host carries LBM_HALO_ROWS ghost
+    // rows per exchange, so a deeper plan (seven / eight iterations per launch) falls back to the three-iteration tile kernel there
+    const bool phys_face = face_south(c) || face_north(c);
+    const bool usable = c->deep && (!phys_face || deep_depth(c->deep) <= (device_transport(c) ? GR : HR1));
+    const int deep = usable ? c->deep : 0, fuse = usable || !c->deep ? c->fuse : std::min(c->fuse, 3);
+    snprintf(name, sizeof(name), "%s", plan_kernel_name(fuse, deep, c->pair_ty, c->use_nt, c->arith, (int)c->esize).c_str());
     return name;
 }
 
@@ -666,7 +701,7 @@ int lbm_debug_plan_candidates(int nx, int ny, int precision, int arith, int num_
     std::string text;
     for (const Plan& pl : plan_candidates(q, none)) {
         const int fuse = pl.fuse > 0 ? pl.fuse : 1;
-        text += pl.name + "|" + plan_option_string(pl.layout, pl.variant, pl.nt, pl.alternate, pl.ty, pl.xcd, fuse, pl.deep, pl.ntl) + "|" +
+        text += pl.name + "|" + plan_option_string(pl.layout, pl.nt, pl.alternate, pl.ty, pl.xcd, fuse, pl.deep, pl.ntl) + "|" +
                 plan_kernel_name(fuse, pl.deep, pl.ty ? pl.ty : 8, pl.nt, arith, q.esize) + "|" + std::to_string(pl.deep ? deep_depth(pl.deep) : fuse) + "\n";
     }
     if ((int)text.size() + 1 > cap) return fail(LBM_ERR_ARG, "buffer too small (%zu bytes needed)", text.size() + 1);
@@ -711,6 +746,76 @@ int lbm_debug_strip_pins(const int* per_rank5, int nranks, int* agreed5) {
     if (!strip_pins_agree(m, &agreed5[0], &agreed5[1], &agreed5[2], &agreed5[3], &agreed5[4]))
         return fail(LBM_ERR_ARG, "the ranks pin different strip schedules");
     return LBM_OK;
+}
+
+/* TEST HOOK (no device needed): dry run of the launch choreography of a strip run and its check (csrc/lbm_choreo.inc.hpp). */
+int lbm_debug_choreography(int nx, int ny, const int* bounds2, int nstrips, int precision, int transport, const char* options,
+                           const int* calls2, int ncalls, int dump, char* out, int cap) {
+    if (!bounds2 || nstrips < 1 || !calls2 || ncalls < 1 || (out && cap < 1) || transport < 0 || transport > 3) return fail(LBM_ERR_ARG, "bad argument");
+    if (transport >= 2 && nstrips != 1) return fail(LBM_ERR_ARG, "transports 2 (one rank of a multi-process run) and 3 (loopback) describe ONE strip");
+    std::vector<lbm_ctx*> cs;
+    Choreo rec;
+    auto cleanup = [&]() { for (lbm_ctx* c : cs) delete c; };
+    for (int k = 0; k < nstrips; ++k) {
+        lbm_ctx* c = choreo_fake_ctx(nx, ny, bounds2[2 * k], bounds2[2 * k + 1], precision, k);
+        cs.push_back(c);
+        if (c->p.y_start < 0 || c->nyl < 1 || c->p.y_start + c->nyl > ny) { cleanup(); return fail(LBM_ERR_ARG, "strip %d outside the lattice", k); }
+        for (const char* q = options ? options : ""; *q;) {        // "key=value key=value"
+            while (*q == ' ') ++q;
+            const char* eq = strchr(q, '=');
+            if (!eq) break;
+            const std::string key(q, eq);
+            char* end = nullptr;
+            const long v = strtol(eq + 1, &end, 10);
+            const int rc = lbm_set_option(c, key.c_str(), v);
+            if (rc) { cleanup(); return rc; }
+            q = end;
+        }
+        c->layout = 1; configure_layout(c, 1);        // strips: row-interleaved
+        if (c->deep) c->fuse = deep_depth(c->deep);
+        if (transport == 2) {      // rank and size as the strip's faces say
+            const bool s_face = c->p.y_start > 0, n_face = c->p.y_start + c->nyl < ny;
+            c->comm = (ncclComm_t)(uintptr_t)0x1;
+            c->nranks = 1 + (s_face ? 1 : 0) + (n_face ? 1 : 0);
+            c->rank = s_face ? 1 : 0;
+        } else if (transport == 3) c->loopback = 1;
+        c->initialised = true;
+        c->cur = 1;
+    }
+    if (transport < 2) {
+        for (int k = 0; k < nstrips; ++k) {
+            cs[(size_t)k]->nb_south = k > 0 ? cs[(size_t)k - 1] : nullptr;
+            cs[(size_t)k]->nb_north = k + 1 < nstrips ? cs[(size_t)k + 1] : nullptr;
+            cs[(size_t)k]->group_transport = transport; cs[(size_t)k]->group_n = nstrips; cs[(size_t)k]->group_threads = 0;
+            const int expect = k == 0 ? 0 : cs[(size_t)k - 1]->p.y_start + cs[(size_t)k - 1]->nyl;
+            if (cs[(size_t)k]->p.y_start != expect || (k + 1 == nstrips && expect + cs[(size_t)k]->nyl != ny)) { cleanup(); return fail(LBM_ERR_ARG, "the strips must cover the lattice bottom to top"); }
+        }
+    }
+    ChoreoChecker chk;
+    chk.init(cs.data(), nstrips);       // (before `rec` is set: the initial state is what lbm_initialise leaves)
+    for (lbm_ctx* c : cs) c->rec = &rec;
+    int rc = LBM_OK;
+    for (int k = 0; k < ncalls && !rc; ++k)
+        rc = DISPATCH(cs[0], do_steps<double>(cs.data(), nstrips, calls2[2 * k], calls2[2 * k + 1]), do_steps<float>(cs.data(), nstrips, calls2[2 * k], calls2[2 * k + 1]));
+    if (rc) { cleanup(); return rc; }
+    chk.run(rec.ops);
+    std::string text;
+    for (const ChoreoViolation& v : chk.bad) {
+        char b[96];
+        if (v.kind == 0) {
+            snprintf(b, sizeof(b), "RACE strip %d buffer %d row %d:\n   ", v.strip, v.buf, v.row);
+            text += b + choreo_op_text(rec.ops[(size_t)v.op_a], v.op_a) + "\n   " + choreo_op_text(rec.ops[(size_t)v.op_b], v.op_b) + "\n";
+        } else {
+            snprintf(b, sizeof(b), "STALE strip %d buffer %d row %d holds iteration %d, wanted %d:\n   ", v.strip, v.buf, v.row, v.have == INT_MIN ? -1 : v.have, v.want);
+            text += b + choreo_op_text(rec.ops[(size_t)v.op_a], v.op_a) + "\n";
+        }
+        if (text.size() > 6000) break;
+    }
+    if (dump) for (int i = 0; i < (int)rec.ops.size(); ++i) text += choreo_op_text(rec.ops[(size_t)i], i) + "\n";
+    if (out) { const size_t m = std::min(text.size(), (size_t)cap - 1); memcpy(out, text.data(), m); out[m] = 0; }
+    const int nbad = (int)chk.bad.size();
+    cleanup();
+    return nbad;
 }
 
 const char* lbm_plan(const lbm_ctx* c) { return c ? c->plan_desc : ""; }

@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(256) k_step_site(const KArgs<T> a) {
 
 // (Rounds 1-3 also had k_step_vec, the same step with 16 bytes per lane — two fp64 / four fp32 sites per thread: 110 us per iteration
 // at 4096x1024 fp64 against 112 for this kernel and 100 for this kernel with non-temporal stores; no measured plan ever took it. Retired
-// in round 4 with its 14 instantiations; option "variant" is accepted and ignored.)
+// in round 4 with its 14 instantiations; round 5 removed the option "variant" that used to select it.)
 
 // Two timesteps per launch: temporal blocking through LDS. A block owns a TX x TY tile of outputs at iteration
 // t+1. Phase 1 computes P_{t+1} on the (TX+2) x (TY+2) region around it from global P_t — the step kernel's

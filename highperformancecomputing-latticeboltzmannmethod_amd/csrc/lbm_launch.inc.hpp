@@ -149,6 +149,11 @@ int launch_step(lbm_ctx* c, int src, int dst, int t, int mode, hipStream_t s) {
 
 template <typename T>
 int launch_forces(lbm_ctx* c, double* out, int t) {
+    if (c->rec) {      // dry run: the force kernel reads this strip's rows of P_t on the compute stream
+        ChoreoOp o; o.kind = ChoreoOp::FORCES; o.strip = c->group_k; o.stream = 0; o.buf = c->cur; o.t = t; o.r0 = 0; o.r1 = c->nyl; o.r_strip = c->group_k;
+        c->rec->ops.push_back(o);
+        return LBM_OK;
+    }
     ForceArgs<T> f;
     f.cur = static_cast<const T*>(c->buf[c->cur]);
     f.plane = (long)c->plane; f.pitch = c->pitch; f.xoff = c->xoff;

@@ -11,14 +11,14 @@
 
 namespace lbmk {
 
-// layout 0 planar / 1 row-interleaved; variant: unused since round 4 (it chose between k_step_vec, retired, and k_step_site); nt: non-temporal stores;
+// layout 0 planar / 1 row-interleaved; nt: non-temporal stores;
 // alternate: walk direction alternates per launch; fuse: iterations per launch of the tile kernels (1..4) or of the deep shape;
 // ty: tile height of the two- / three-iteration tile kernels (8 or 12); xcd: XCD-aware tile walk; deep: 0, or the deep shape
 // (1..3: k_stepd_tile six / seven / eight iterations; 6 / 7: k_stepc_col five / six iterations in registers on 64x32 regions;
 // 9: the same kernel with SEVEN iterations as the plan's depth — the largest grids; 8: fp32 only, k_stepc_col seven iterations
 // on TALL 64x48 regions — lbm_col_api.hpp); ntl: the register kernel's level-1 loads
 // are non-temporal
-struct Plan { int layout, variant, nt, alternate, fuse, ty, xcd; std::string name; int deep = 0; int ntl = 0; };
+struct Plan { int layout, nt, alternate, fuse, ty, xcd; std::string name; int deep = 0; int ntl = 0; };
 
 inline bool deep_is_col(int id) { return id >= 6 && id <= 9; }
 inline bool deep_is_tall(int id) { return id == 8; }
@@ -62,67 +62,67 @@ inline std::vector<Plan> plan_candidates(const PlanQuery& q, const Plan& fixed) 
     const std::string deep_name = strip_deep == 7 ? "row-interleaved/6-step 64x32 in registers" : "row-interleaved/6-step 64x16";
     if (!q.tune) { cand.push_back(fixed); return cand; }
     if (!q.can_tune) {
-        if (strip_deep) cand.push_back({1, 1, 1, 0, 6, 12, 1, deep_name + " (default, not measured)", strip_deep});
-        else if (q.strips) cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved (default, not measured)"});
-        else cand.push_back({0, 1, 1, 0, 3, 12, 0, "planar (default, not measured)"});
+        if (strip_deep) cand.push_back({1, 1, 0, 6, 12, 1, deep_name + " (default, not measured)", strip_deep});
+        else if (q.strips) cand.push_back({1, 1, 0, 3, 12, 1, "row-interleaved (default, not measured)"});
+        else cand.push_back({0, 1, 0, 3, 12, 0, "planar (default, not measured)"});
         return cand;
     }
     // Strips exchange GR rows x 9 sub-rows as one contiguous run: row-interleaved only. Every rank must issue the same
     // sequence of launches (one exchange per launch), so the fusion depth and tile shape of a strip run are fixed by rule;
     // only rank-local choices (the store policy) are measured.
     if (strip_deep) {
-        cand.push_back({1, 1, 1, 0, 6, 12, 1, deep_name + "/nt-store/xcd", strip_deep});
-        cand.push_back({1, 1, 0, 0, 6, 12, 1, deep_name + "/xcd", strip_deep});
-        if (strip_deep == 7) cand.push_back({1, 1, 0, 0, 6, 12, 1, deep_name + "/nt-load/xcd", strip_deep, 1});
+        cand.push_back({1, 1, 0, 6, 12, 1, deep_name + "/nt-store/xcd", strip_deep});
+        cand.push_back({1, 0, 0, 6, 12, 1, deep_name + "/xcd", strip_deep});
+        if (strip_deep == 7) cand.push_back({1, 0, 0, 6, 12, 1, deep_name + "/nt-load/xcd", strip_deep, 1});
         return cand;
     }
     if (q.strips) {
-        cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
-        cand.push_back({1, 1, 1, 0, 3, 12, 0, "row-interleaved/3-step 64x12/nt-store"});
-        cand.push_back({1, 1, 0, 1, 3, 12, 1, "row-interleaved/3-step 64x12/alternate/xcd"});
+        cand.push_back({1, 1, 0, 3, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
+        cand.push_back({1, 1, 0, 3, 12, 0, "row-interleaved/3-step 64x12/nt-store"});
+        cand.push_back({1, 0, 1, 3, 12, 1, "row-interleaved/3-step 64x12/alternate/xcd"});
         return cand;
     }
-    cand.push_back({1, 1, 1, 0, 4, 8, 1, "row-interleaved/4-step 64x8/nt-store/xcd"});
-    cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-store/xcd", 7});   // k_stepc_col
-    cand.push_back({1, 1, 1, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/nt-store/xcd", 6});
+    cand.push_back({1, 1, 0, 4, 8, 1, "row-interleaved/4-step 64x8/nt-store/xcd"});
+    cand.push_back({1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-store/xcd", 7});   // k_stepc_col
+    cand.push_back({1, 1, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/nt-store/xcd", 6});
     // (non-temporal stores pay where most of the lattice fits the 256 MiB Infinity Cache — 4096x1024 fp64: +1 % — and
     // cost 3-12 % on the large grids: 8192x2048 fp64 168 -> 173 GLUPS, 16384x4096 fp32 259 -> 290 without them)
-    cand.push_back({1, 1, 0, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/xcd", 7});
-    cand.push_back({1, 1, 0, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/xcd", 6});
-    cand.push_back({1, 1, 0, 1, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/alternate/xcd", 7});
+    cand.push_back({1, 0, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/xcd", 7});
+    cand.push_back({1, 0, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/xcd", 6});
+    cand.push_back({1, 0, 1, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/alternate/xcd", 7});
     // (round 4: non-temporal level-1 LOADS with plain stores: 164-167 against 158-163 GLUPS at 4096x1024 fp64)
-    cand.push_back({1, 1, 0, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-load/xcd", 7, 1});
-    cand.push_back({1, 1, 0, 1, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-load/alternate/xcd", 7, 1});
-    cand.push_back({1, 1, 0, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/nt-load/xcd", 6, 1});
+    cand.push_back({1, 0, 0, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-load/xcd", 7, 1});
+    cand.push_back({1, 0, 1, 6, 12, 1, "row-interleaved/6-step 64x32 in registers/nt-load/alternate/xcd", 7, 1});
+    cand.push_back({1, 0, 0, 5, 12, 1, "row-interleaved/5-step 64x32 in registers/nt-load/xcd", 6, 1});
     // (round 4: seven iterations as the plan's own depth pay on the largest grids — 8192x2048 fp64 175.9 GLUPS against 169.9 for six;
     // at 4096x1024 they lose, 157-160 against 160-166)
     if (!small_grid) {
-        cand.push_back({1, 1, 0, 0, 7, 12, 1, "row-interleaved/7-step 64x32 in registers/xcd", 9});
-        cand.push_back({1, 1, 0, 1, 7, 12, 1, "row-interleaved/7-step 64x32 in registers/alternate/xcd", 9});
+        cand.push_back({1, 0, 0, 7, 12, 1, "row-interleaved/7-step 64x32 in registers/xcd", 9});
+        cand.push_back({1, 0, 1, 7, 12, 1, "row-interleaved/7-step 64x32 in registers/alternate/xcd", 9});
     }
     // (round 4, fp32: 64x48 regions on twelve waves — 16384x4096 320 GLUPS against 289-298 on 64x32; 4096x1024 262 against 260)
     if (q.esize == 4 && !small_grid) {
-        cand.push_back({1, 1, 0, 0, 7, 12, 1, "row-interleaved/7-step 64x48 in registers/xcd", 8});
-        cand.push_back({1, 1, 0, 1, 7, 12, 1, "row-interleaved/7-step 64x48 in registers/alternate/xcd", 8});
+        cand.push_back({1, 0, 0, 7, 12, 1, "row-interleaved/7-step 64x48 in registers/xcd", 8});
+        cand.push_back({1, 0, 1, 7, 12, 1, "row-interleaved/7-step 64x48 in registers/alternate/xcd", 8});
     }
-    cand.push_back({1, 1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x16/nt-store/xcd", 1});
+    cand.push_back({1, 1, 0, 6, 12, 1, "row-interleaved/6-step 64x16/nt-store/xcd", 1});
     if (small_grid && !q.faces) {   // one round of LDS-filling tiles: a launch's load and store phases are paid once per 7-8 iterations
-        cand.push_back({1, 1, 1, 0, 7, 12, 1, "row-interleaved/7-step 64x16/nt-store/xcd", 2});
-        cand.push_back({1, 1, 1, 0, 8, 12, 1, "row-interleaved/8-step 32x32/nt-store/xcd", 3});
+        cand.push_back({1, 1, 0, 7, 12, 1, "row-interleaved/7-step 64x16/nt-store/xcd", 2});
+        cand.push_back({1, 1, 0, 8, 12, 1, "row-interleaved/8-step 32x32/nt-store/xcd", 3});
     }
-    cand.push_back({1, 1, 1, 0, 3, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
-    cand.push_back({1, 1, 1, 0, 3, 8, 1, "row-interleaved/3-step 64x8/nt-store/xcd"});
-    cand.push_back({1, 1, 1, 0, 2, 12, 1, "row-interleaved/2-step 64x12/nt-store/xcd"});
-    cand.push_back({1, 1, 1, 0, 2, 8, 1, "row-interleaved/2-step 64x8/nt-store/xcd"});
-    cand.push_back({1, 1, 1, 0, 1, 0, 0, "row-interleaved/site/nt-store"});
-    cand.push_back({1, 1, 0, 1, 1, 0, 0, "row-interleaved/site/alternate"});
-    cand.push_back({0, 0, 1, 0, 4, 8, 1, "planar/4-step 64x8/nt-store/xcd"});
-    cand.push_back({0, 0, 1, 0, 6, 12, 1, "planar/6-step 64x32 in registers/nt-store/xcd", 7});
-    cand.push_back({0, 0, 1, 0, 3, 12, 1, "planar/3-step 64x12/nt-store/xcd"});
-    cand.push_back({0, 0, 1, 0, 3, 12, 0, "planar/3-step 64x12/nt-store"});
-    cand.push_back({0, 0, 1, 0, 2, 12, 0, "planar/2-step 64x12/nt-store"});
-    cand.push_back({0, 0, 0, 1, 3, 12, 0, "planar/3-step 64x12/alternate"});
-    cand.push_back({0, 1, 0, 1, 1, 0, 0, "planar/site/alternate"});
+    cand.push_back({1, 1, 0, 3, 12, 1, "row-interleaved/3-step 64x12/nt-store/xcd"});
+    cand.push_back({1, 1, 0, 3, 8, 1, "row-interleaved/3-step 64x8/nt-store/xcd"});
+    cand.push_back({1, 1, 0, 2, 12, 1, "row-interleaved/2-step 64x12/nt-store/xcd"});
+    cand.push_back({1, 1, 0, 2, 8, 1, "row-interleaved/2-step 64x8/nt-store/xcd"});
+    cand.push_back({1, 1, 0, 1, 0, 0, "row-interleaved/site/nt-store"});
+    cand.push_back({1, 0, 1, 1, 0, 0, "row-interleaved/site/alternate"});
+    cand.push_back({0, 1, 0, 4, 8, 1, "planar/4-step 64x8/nt-store/xcd"});
+    cand.push_back({0, 1, 0, 6, 12, 1, "planar/6-step 64x32 in registers/nt-store/xcd", 7});
+    cand.push_back({0, 1, 0, 3, 12, 1, "planar/3-step 64x12/nt-store/xcd"});
+    cand.push_back({0, 1, 0, 3, 12, 0, "planar/3-step 64x12/nt-store"});
+    cand.push_back({0, 1, 0, 2, 12, 0, "planar/2-step 64x12/nt-store"});
+    cand.push_back({0, 0, 1, 3, 12, 0, "planar/3-step 64x12/alternate"});
+    cand.push_back({0, 0, 1, 1, 0, 0, "planar/site/alternate"});
     return cand;
 }
 
@@ -141,9 +141,9 @@ inline std::string plan_kernel_name(int fuse, int deep, int pair_ty, int nt, int
 }
 
 // the plan as lbm_set_option pairs: `deep` (which sets the depth of its launches itself) or `fuse`, never both
-inline std::string plan_option_string(int layout, int variant, int nt, int alternate, int pair_ty, int xcd, int fuse, int deep, int ntl = 0) {
+inline std::string plan_option_string(int layout, int nt, int alternate, int pair_ty, int xcd, int fuse, int deep, int ntl = 0) {
     char b[128];
-    snprintf(b, sizeof(b), "layout=%d variant=%d nt=%d alternate=%d pair_ty=%d xcd=%d", layout, variant, nt, alternate, pair_ty ? pair_ty : 8, xcd);
+    snprintf(b, sizeof(b), "layout=%d nt=%d alternate=%d pair_ty=%d xcd=%d", layout, nt, alternate, pair_ty ? pair_ty : 8, xcd);
     std::string s(b);
     if (deep) s += " deep=" + std::to_string(deep);
     else s += " fuse=" + std::to_string(fuse > 0 && fuse <= 4 ? fuse : 1);

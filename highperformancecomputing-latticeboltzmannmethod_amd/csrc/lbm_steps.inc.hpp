@@ -23,7 +23,7 @@ inline void graph_drop(lbm_ctx* c) {
 // May the next `GRAPH_GROUPS` groups of this context be replayed? (a single context with a device transport on a deep plan
 // that exchanges after every launch, far from the end of the call and from any force output)
 inline bool graph_wanted(const lbm_ctx* c, int remaining, int of, bool transport) {
-    if (!c->use_graph || c->graph_failed || !transport || c->group_n > 1) return false;
+    if (!c->use_graph || c->graph_failed || !transport || c->group_n > 1 || c->rec) return false;
     // RCCL send/recv between REAL peers under stream capture has never run anywhere (this round's boxes have one GPU; the
     // one-rank communicator sending to itself captures and replays fine): a multi-rank run takes the graph path only when
     // asked to ("graph" 2) — a refused capture falls back, a hang in an untested collective path would not.
@@ -118,7 +118,7 @@ template <typename T>
 int do_steps(lbm_ctx** cs, int n, int nsteps, int of) {
     for (int i = 0; i < n; ++i) {
         lbm_ctx* c = cs[i];
-        HIPCHK(hipSetDevice(c->device));
+        SETDEV(c);
         if (c->timing) HIPCHK(hipEventRecord(c->ev_t0, c->stream));
         if (c->steps_done != cs[0]->steps_done) return fail(LBM_ERR_ARG, "the strips of a group are at different iterations");
     }
@@ -131,11 +131,28 @@ int do_steps(lbm_ctx** cs, int n, int nsteps, int of) {
         // issuing for 8 GPUs in turn cannot hide behind 20 us kernels. Three rendezvous per launch: every strip's
         // ev_edge is recorded before anybody pulls, every pull is queued before anybody records ev_comm / launches the
         // interior, and every ev_comm is recorded before the next launch looks at its neighbours'.
-        GroupPool& P = *c0->pool;
-        const std::function<void(int)> worker = [&](int i) {
+        // Between two rendezvous NO path returns: every error of a strip goes through report() and the whole group leaves at the
+        // next rendezvous, decided once by its last arrival (GroupPool). The job's state lives on the heap, owned by the closure:
+        // a thread that comes back after the call has timed out (LBM_ERR_TIMEOUT) still finds it.
+        struct Job { std::vector<lbm_ctx*> cs; std::vector<Launch> L; int n, nsteps, of; bool transport; int launches = 0; };
+        auto J = std::make_shared<Job>();
+        J->cs.assign(cs, cs + n); J->L.resize((size_t)n); J->n = n; J->nsteps = nsteps; J->of = of; J->transport = transport;
+        const std::function<void(GroupPool::State&, int)> worker = [J](GroupPool::State& P, int i) {
+            lbm_ctx** cs = J->cs.data();
+            std::vector<Launch>& L = J->L;
+            const int n = J->n, nsteps = J->nsteps, of = J->of;
+            const bool transport = J->transport;
             lbm_ctx* c = cs[i];
+            lbm_ctx* c0 = cs[0];
             (void)hipSetDevice(c->device);
-            for (int k = 0; k < nsteps;) {
+            auto fault = [&](int launch, int point) -> int {       // TEST ONLY ("debug_fault_*"): this strip fails or sleeps here
+                if (c->debug_fault_launch != launch || c->debug_fault_point != point) return LBM_OK;
+                c->debug_fault_launch = -1;
+                if (c->debug_fault_stall_ms > 0) { std::this_thread::sleep_for(std::chrono::milliseconds(c->debug_fault_stall_ms)); return LBM_OK; }
+                return fail(LBM_ERR_HIP, "injected fault: strip %d, launch %d, point %d", i, launch, point);
+            };
+            int launch = 0;
+            for (int k = 0; k < nsteps; ++launch) {
                 const int t = c->steps_done;
                 int rc = LBM_OK;
                 if (of > 0 && t % of == 0) {
@@ -146,8 +163,9 @@ int do_steps(lbm_ctx** cs, int n, int nsteps, int of) {
                 }
                 if (!rc) rc = plan_launch(c, nsteps - k, of, transport, true, &L[(size_t)i]);
                 if (!rc) rc = issue_before<T>(c, L[(size_t)i]);
+                if (!rc) rc = fault(launch, 0);
                 P.report(rc, g_err);
-                if (P.arrive()) return;
+                if (P.arrive(i, launch, 1)) return;
                 if (L[(size_t)i].depth != L[0].depth || L[(size_t)i].kind != L[0].kind)
                     P.report(fail(LBM_ERR_ARG, "the strips of a group disagree on the next launch (different options?)"), g_err);
                 else if (L[0].kind == KIND_EXCHANGE) {
@@ -156,15 +174,18 @@ int do_steps(lbm_ctx** cs, int n, int nsteps, int of) {
                     else if (i == 0) rc2 = exchange_group<T>(cs, n, L[0].dst);      // RCCL: one group call, one thread
                     P.report(rc2, g_err);
                 }
-                if (P.arrive()) return;
+                P.report(fault(launch, 1), g_err);
+                if (P.arrive(i, launch, 2)) return;
                 P.report(issue_after<T>(c, L[(size_t)i]), g_err);
-                if (P.arrive()) return;
+                P.report(fault(launch, 2), g_err);
+                if (P.arrive(i, launch, 3)) return;
                 k += L[(size_t)i].depth;       // (its own copy: strip 0 may already be planning the next launch into L[0])
-                if (i == 0) ++launches;
+                if (i == 0) ++J->launches;
             }
         };
-        P.run(worker);
-        if (P.err.load() != LBM_OK) return fail(P.err.load(), "%s", P.msg.c_str());
+        const int prc = c0->pool->run(worker, c0->wait_timeout_ms);
+        launches = J->launches;
+        if (prc != LBM_OK) return prc;
         HIPCHK(hipSetDevice(c0->device));
     } else
     for (int k = 0; k < nsteps;) {
@@ -176,7 +197,7 @@ int do_steps(lbm_ctx** cs, int n, int nsteps, int of) {
         }
         for (int i = 0; i < n; ++i) {
             lbm_ctx* c = cs[i];
-            HIPCHK(hipSetDevice(c->device));
+            SETDEV(c);
             if (of > 0 && t % of == 0) {
                 if (c->log_count >= c->log_cap) return fail(LBM_ERR_ARG, "force log full (%d rows): drain it", c->log_cap);
                 int rc = join_comm(c);      // the edge bands of the previous launch live on the side stream
@@ -197,7 +218,7 @@ int do_steps(lbm_ctx** cs, int n, int nsteps, int of) {
             if (rc) return rc;
         }
         for (int i = 0; i < n; ++i) {
-            HIPCHK(hipSetDevice(cs[i]->device));
+            SETDEV(cs[i]);
             int rc = issue_after<T>(cs[i], L[i]);
             if (rc) return rc;
         }

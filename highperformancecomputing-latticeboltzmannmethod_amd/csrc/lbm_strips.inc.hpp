@@ -36,11 +36,57 @@ inline FaceSpans face_spans(const lbm_ctx* c) {
     return f;
 }
 
+// ---- what is queued goes through these: the runtime call, or — dry run (lbm_ctx::rec) — an entry of the choreography record
+#define QCHK(expr) do { const int q_ = (expr); if (q_) return q_; } while (0)
+#define SETDEV(c) do { if (!(c)->rec) HIPCHK(hipSetDevice((c)->device)); } while (0)
+#define LAUNCHED(c) do { if (!(c)->rec) HIPCHK(hipGetLastError()); } while (0)
+inline int stream_id(const lbm_ctx* c, hipStream_t s) { return s == c->stream ? 0 : 1; }
+inline int q_record(lbm_ctx* c, hipEvent_t e, hipStream_t s) {
+    if (c->rec) {
+        ChoreoOp o; o.kind = ChoreoOp::RECORD; o.strip = c->group_k; o.stream = stream_id(c, s); o.ev_strip = c->group_k;
+        o.ev = e == c->ev_main ? 0 : e == c->ev_edge ? 1 : 2;
+        c->rec->ops.push_back(o);
+        return LBM_OK;
+    }
+    HIPCHK(hipEventRecord(e, s));
+    return LBM_OK;
+}
+inline int q_wait(lbm_ctx* c, hipStream_t s, const lbm_ctx* owner, hipEvent_t e) {
+    if (c->rec) {
+        ChoreoOp o; o.kind = ChoreoOp::WAIT; o.strip = c->group_k; o.stream = stream_id(c, s); o.ev_strip = owner->group_k;
+        o.ev = e == owner->ev_main ? 0 : e == owner->ev_edge ? 1 : 2;
+        c->rec->ops.push_back(o);
+        return LBM_OK;
+    }
+    HIPCHK(hipStreamWaitEvent(s, e, 0));
+    return LBM_OK;
+}
+// rows of a FaceSpans offset (elements from the buffer's start; row-interleaved layout: a row is `pitch` elements)
+inline int span_row(const lbm_ctx* c, long off) { return (int)(off / c->pitch) - GR; }
+inline void rec_xfer(lbm_ctx* c, int kind, hipStream_t s, int buf, long write_off, long read_off, int rows, const lbm_ctx* from) {
+    ChoreoOp o; o.kind = kind; o.strip = c->group_k; o.stream = stream_id(c, s); o.buf = buf;
+    if (write_off >= 0) { o.w0[0] = span_row(c, write_off); o.w1[0] = o.w0[0] + rows; }
+    if (read_off >= 0) { o.r0 = span_row(from ? from : c, read_off); o.r1 = o.r0 + rows; }
+    o.r_strip = from ? from->group_k : -1;
+    c->rec->ops.push_back(o);
+}
+
 // Transports of ONE context: RCCL send/recv between processes (rank r <-> r-1, r+1), or the test-only loopbacks.
 template <typename T>
 int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
     if (c->skip_exchange) return LBM_OK;
     const FaceSpans f = face_spans(c);
+    if (c->rec) {       // dry run: one rank of a multi-process run (its neighbours are other processes), or the device-copy loopback
+        const int hr = halo_rows(c);
+        if (c->loopback) {
+            rec_xfer(c, ChoreoOp::COPY, s, dst, f.ghost_s, f.top_rows, hr, c);
+            rec_xfer(c, ChoreoOp::COPY, s, dst, f.ghost_n, f.bot_rows, hr, c);
+        } else if (c->nranks > 1) {
+            if (c->rank + 1 < c->nranks) { rec_xfer(c, ChoreoOp::SEND, s, dst, -1, f.top_rows, hr, nullptr); rec_xfer(c, ChoreoOp::RECV, s, dst, f.ghost_n, -1, hr, nullptr); }
+            if (c->rank > 0) { rec_xfer(c, ChoreoOp::SEND, s, dst, -1, f.bot_rows, hr, nullptr); rec_xfer(c, ChoreoOp::RECV, s, dst, f.ghost_s, -1, hr, nullptr); }
+        }
+        return LBM_OK;
+    }
     T* b = static_cast<T*>(c->buf[dst]);
     const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
     if (c->loopback) {   // test transports: my own edge rows become my ghost rows
@@ -87,14 +133,15 @@ template <typename T>
 int pull_halos(lbm_ctx** cs, int n, int k, int dst) {
     lbm_ctx* c = cs[k];
     if (c->skip_exchange) return LBM_OK;
-    HIPCHK(hipSetDevice(c->device));
+    SETDEV(c);
     const FaceSpans f = face_spans(c);
     T* b = static_cast<T*>(c->buf[dst]);
     hipStream_t s = exchange_stream(c);
     const size_t bytes = f.cnt * sizeof(T);
     auto pull = [&](lbm_ctx* nb, long nb_rows, long my_ghost) -> int {
         const T* src = static_cast<const T*>(nb->buf[dst]) + nb_rows;
-        HIPCHK(hipStreamWaitEvent(s, nb->ev_edge, 0));            // the neighbour's edge rows of this launch are written
+        QCHK(q_wait(c, s, nb, nb->ev_edge));            // the neighbour's edge rows of this launch are written
+        if (c->rec) { rec_xfer(c, ChoreoOp::COPY, s, dst, my_ghost, nb_rows, halo_rows(c), nb); return LBM_OK; }
         if (nb->device == c->device) HIPCHK(hipMemcpyAsync(b + my_ghost, src, bytes, hipMemcpyDeviceToDevice, s));
         else HIPCHK(hipMemcpyPeerAsync(b + my_ghost, c->device, src, nb->device, bytes, s));
         return LBM_OK;
@@ -107,6 +154,17 @@ int pull_halos(lbm_ctx** cs, int n, int k, int dst) {
 template <typename T>
 int exchange_group(lbm_ctx** cs, int n, int dst) {
     if (n < 2 || cs[0]->skip_exchange) return LBM_OK;
+    if (cs[0]->group_transport == 1 && cs[0]->rec) {      // dry run: every member's sends (reads) and receives (writes) on its exchange stream
+        for (int k = 0; k < n; ++k) {
+            lbm_ctx* c = cs[k];
+            const FaceSpans f = face_spans(c);
+            const int hr = halo_rows(c);
+            hipStream_t s = exchange_stream(c);
+            if (k + 1 < n) { rec_xfer(c, ChoreoOp::SEND, s, dst, -1, f.top_rows, hr, nullptr); rec_xfer(c, ChoreoOp::RECV, s, dst, f.ghost_n, face_spans(cs[k + 1]).bot_rows, hr, cs[k + 1]); }
+            if (k > 0) { rec_xfer(c, ChoreoOp::SEND, s, dst, -1, f.bot_rows, hr, nullptr); rec_xfer(c, ChoreoOp::RECV, s, dst, f.ghost_s, face_spans(cs[k - 1]).top_rows, hr, cs[k - 1]); }
+        }
+        return LBM_OK;
+    }
     if (cs[0]->group_transport == 1) {
         const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
         NCCLCHK(ncclGroupStart());
@@ -164,6 +222,13 @@ inline bool face_north(const lbm_ctx* c) { return c->p.y_start + c->nyl < c->p.n
 
 template <typename T>
 void launch_depth(const lbm_ctx* c, const KArgs<T>& a, int depth, hipStream_t s) {
+    if (c->rec) {
+        ChoreoOp o; o.kind = ChoreoOp::KERNEL; o.strip = c->group_k; o.stream = stream_id(c, s); o.buf = a.dst == c->buf[0] ? 0 : 1;
+        o.t = a.t; o.depth = depth;
+        o.w0[0] = a.y_lo; o.w1[0] = a.y_lo + a.y_cnt; o.w0[1] = a.y_lo2; o.w1[1] = a.y_lo2 + a.y_cnt2;
+        c->rec->ops.push_back(o);
+        return;
+    }
     if (depth > 1) launch_fused_rows<T>(c, a, depth, s);
     else launch_rows<T, MODE_STEP>(c, a, s);
 }
@@ -273,14 +338,15 @@ int issue_before(lbm_ctx* c, const Launch& L) {
     if (L.kind == KIND_LOCAL) {
         a.reverse = rev;
         launch_depth<T>(c, a, L.depth, c->stream);
-        HIPCHK(hipGetLastError());
+        LAUNCHED(c);
         return LBM_OK;
     }
     // one tile band — and at least the rows that travel: the exchange reads them behind ev_edge, i.e. behind the EDGE launch only.
     // (Round 4: with twelve- and eight-row exchanges a remainder launch of one iteration, whose band used to be six rows, left the
     // rows beyond them to the interior launch — a race with the neighbour's pull that showed as a 1-in-15 mismatch of a threaded
     // group across force outputs.)
-    const int E = std::max(c->deep_now ? deep_rows(c, c->deep, L.depth) : L.depth > 1 ? c->pair_ty : HR1, halo_rows(c));
+    const int band = c->deep_now ? deep_rows(c, c->deep, L.depth) : L.depth > 1 ? c->pair_ty : HR1;
+    const int E = c->debug_old_edge_band ? band : std::max(band, halo_rows(c));      // (TEST ONLY: the rule as it was before the fix)
     if (L.kind == KIND_EXTENDED) {   // all rows of the strip PLUS the ext_rows ghost rows next to each internal face
         const int es = face_south(c) ? ext_rows(c) : 0, en = face_north(c) ? ext_rows(c) : 0;
         int e0 = face_south(c) ? E : 0, e1 = face_north(c) ? E : 0;
@@ -290,13 +356,13 @@ int issue_before(lbm_ctx* c, const Launch& L) {
             // follow the exchange on the side stream. The next launch waits for ev_edge.
             a.y_lo = e0; a.y_cnt = c->nyl - e0 - e1; a.reverse = rev;
             launch_depth<T>(c, a, L.depth, c->stream);
-            HIPCHK(hipGetLastError());
+            LAUNCHED(c);
             KArgs<T> b = make_kargs<T>(c, L.src, L.dst, L.t);
             b.y_lo = -es; b.y_cnt = e0 + es; b.y_lo2 = c->nyl - e1; b.y_cnt2 = e1 + en;
             if (b.y_cnt == 0) { b.y_lo = b.y_lo2; b.y_cnt = b.y_cnt2; b.y_cnt2 = 0; }
             launch_depth<T>(c, b, L.depth, c->comm_stream);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(c->ev_edge, c->comm_stream));
+            LAUNCHED(c);
+            QCHK(q_record(c, c->ev_edge, c->comm_stream));
             c->ext_split_pending = true;
             return LBM_OK;
         }
@@ -306,13 +372,13 @@ int issue_before(lbm_ctx* c, const Launch& L) {
         a.y_cnt = c->nyl + es + en;
         a.reverse = rev;
         launch_depth<T>(c, a, L.depth, c->stream);
-        HIPCHK(hipGetLastError());
+        LAUNCHED(c);
         return LBM_OK;
     }
     hipStream_t es = exchange_stream(c);
     auto wait_for_neighbour_pulls = [&](hipStream_t s) -> int {   // group / peer: my edge rows of buf[dst] may still be being read
         for (lbm_ctx* nb : {c->nb_south, c->nb_north})
-            if (nb && c->group_transport == 0 && nb->comm_issued) HIPCHK(hipStreamWaitEvent(s, nb->ev_comm, 0));
+            if (nb && c->group_transport == 0 && nb->comm_issued) QCHK(q_wait(c, s, nb, nb->ev_comm));
         return LBM_OK;
     };
     if (c->overlap != 1) {
@@ -324,11 +390,11 @@ int issue_before(lbm_ctx* c, const Launch& L) {
         if (rc) return rc;
         a.reverse = rev;
         launch_depth<T>(c, a, L.depth, c->stream);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(c->ev_edge, c->stream));
+        LAUNCHED(c);
+        QCHK(q_record(c, c->ev_edge, c->stream));
         if (c->overlap == 2) {
-            HIPCHK(hipEventRecord(c->ev_main, c->stream));
-            HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_main, 0));
+            QCHK(q_record(c, c->ev_main, c->stream));
+            QCHK(q_wait(c, c->comm_stream, c, c->ev_main));
         }
         return LBM_OK;
     }
@@ -338,17 +404,17 @@ int issue_before(lbm_ctx* c, const Launch& L) {
     // register kernel throughout: the interior blocks share the CUs with the edge blocks either way. Not kept.)
     int e0 = has_s ? E : 0, e1 = has_n ? E : 0;
     if (e0 + e1 >= c->nyl) { e0 = c->nyl; e1 = 0; }          // short strip: everything is edge
-    HIPCHK(hipEventRecord(c->ev_main, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_main, 0));
-    if (c->comm_issued) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_edge, 0));   // ev_edge still is the previous group's
+    QCHK(q_record(c, c->ev_main, c->stream));
+    QCHK(q_wait(c, c->comm_stream, c, c->ev_main));
+    if (c->comm_issued) QCHK(q_wait(c, c->stream, c, c->ev_edge));   // ev_edge still is the previous group's
     int rc = wait_for_neighbour_pulls(es);
     if (rc) return rc;
     a.reverse = 0;
     a.y_lo = 0; a.y_cnt = e0; a.y_lo2 = c->nyl - e1; a.y_cnt2 = e1;
     if (e0 == 0) { a.y_lo = a.y_lo2; a.y_cnt = e1; a.y_cnt2 = 0; }
     launch_depth<T>(c, a, L.depth, c->comm_stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev_edge, c->comm_stream));
+    LAUNCHED(c);
+    QCHK(q_record(c, c->ev_edge, c->comm_stream));
     c->edge_rows[0] = e0; c->edge_rows[1] = e1;
     return LBM_OK;
 }
@@ -357,7 +423,7 @@ int issue_before(lbm_ctx* c, const Launch& L) {
 template <typename T>
 int issue_after(lbm_ctx* c, const Launch& L) {
     if (L.kind == KIND_EXCHANGE) {
-        HIPCHK(hipEventRecord(c->ev_comm, exchange_stream(c)));
+        QCHK(q_record(c, c->ev_comm, exchange_stream(c)));
         c->comm_issued = true;
         if (c->overlap == 1) {
             const int e0 = c->edge_rows[0], e1 = c->edge_rows[1];
@@ -366,7 +432,7 @@ int issue_after(lbm_ctx* c, const Launch& L) {
                 a.y_lo = e0; a.y_cnt = c->nyl - e0 - e1;
                 a.reverse = (c->alternate && (c->launches_total & 1)) ? 1 : 0;
                 launch_depth<T>(c, a, L.depth, c->stream);
-                HIPCHK(hipGetLastError());
+                LAUNCHED(c);
             }
         }
     }
@@ -399,10 +465,10 @@ int advance(lbm_ctx* c, int remaining, int of, bool transport, bool strip_logic 
 // Make everything issued so far (both streams) visible to work queued on the compute stream afterwards.
 inline int join_comm(lbm_ctx* c) {
     if (c->ext_split_pending) {   // overlap 2: the edge bands of the last extended launch (queued behind the exchange)
-        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_edge, 0));
+        QCHK(q_wait(c, c->stream, c, c->ev_edge));
         c->ext_split_pending = false;
     }
-    if (c->comm_issued) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+    if (c->comm_issued) QCHK(q_wait(c, c->stream, c, c->ev_comm));
     return LBM_OK;
 }
 

@@ -10,7 +10,7 @@
 
 inline void apply_plan(lbm_ctx* c, const Plan& pl) {
     configure_layout(c, pl.layout);
-    c->variant = pl.variant; c->use_nt = pl.nt; c->use_ntl = pl.ntl; c->alternate = pl.alternate; c->fuse = pl.fuse > 0 ? pl.fuse : 1; c->xcd = pl.xcd;
+    c->use_nt = pl.nt; c->use_ntl = pl.ntl; c->alternate = pl.alternate; c->fuse = pl.fuse > 0 ? pl.fuse : 1; c->xcd = pl.xcd;
     if (pl.ty) c->pair_ty = pl.ty;
     c->deep = pl.deep;
 }
@@ -50,7 +50,7 @@ int time_plan(lbm_ctx* c, float* ms_out, int window = 36) {
 template <typename T>
 int choose_plan(lbm_ctx* c) {
     const bool strips = (c->comm && c->nranks > 1) || c->group_n > 1 || c->loopback;
-    const Plan fixed = {(strips || c->loopback) ? 1 : c->layout, c->variant, c->use_nt, c->alternate, c->fuse, c->pair_ty, c->xcd,
+    const Plan fixed = {(strips || c->loopback) ? 1 : c->layout, c->use_nt, c->alternate, c->fuse, c->pair_ty, c->xcd,
                         "fixed by options", c->deep, c->use_ntl};
     const bool p2 = pair_possible(c);
     (void)p2;
@@ -129,7 +129,7 @@ int choose_plan(lbm_ctx* c) {
     else if (cand.size() > 1) snprintf(c->plan_desc, sizeof(c->plan_desc), "%s (fastest of %zu measured, %.1f us/iteration)",
                                        cand[best].name.c_str(), cand.size(), best_ms * 1e3f);
     else snprintf(c->plan_desc, sizeof(c->plan_desc), "%s", cand[best].name.c_str());
-    snprintf(c->plan_opts, sizeof(c->plan_opts), "%s", plan_option_string(c->layout, c->variant, c->use_nt, c->alternate, c->pair_ty, c->xcd, c->fuse, c->deep, c->use_ntl).c_str());
+    snprintf(c->plan_opts, sizeof(c->plan_opts), "%s", plan_option_string(c->layout, c->use_nt, c->alternate, c->pair_ty, c->xcd, c->fuse, c->deep, c->use_ntl).c_str());
     if (cand.size() > 1 && c->deep && !strips && best_ms > 0.f) {
         // What the shallow launches cost on THIS grid and allocation, for plan_launch's split of a segment's last iterations
         // (a single domain only: the strips of a run must all split alike, so they keep the fixed table).
@@ -215,14 +215,21 @@ int tune_strip_schedule(lbm_ctx* c) {
         if (pd) c->deep_halo = dh;
         if (!go || (po && pd)) return LBM_OK;
     }
+    // (every error return below leaves the context as it came: a trial changes trailing_pair and — the depth trial — deep and fuse)
+    struct Restore { lbm_ctx* c; int tp, deep, fuse; bool armed = true;
+                     ~Restore() { if (armed) { c->trailing_pair = tp; c->deep = deep; c->fuse = fuse; } } } guard{c, c->trailing_pair, c->deep, c->fuse};
     const int keep_tp = c->trailing_pair;
     c->trailing_pair = 1;
     constexpr int WARM = 60, TIMED = 240;      // (the warm-up is long enough to take the one-off graph capture of a schedule)
+    int frame_rows = halo_rows(c);             // ghost rows per face that the exchanges so far have kept fresh
     auto trial = [&](int o, int d, double* worst_ms) -> int {
-        const int rows_before = halo_rows(c);
         c->overlap = o; c->deep_halo = d;
         int rc = LBM_OK;
-        if (halo_rows(c) != rows_before) {      // the schedule on trial refreshes a deeper ghost frame: fill it before its first launch reads it
+        // (this used to compare with halo_rows(c) read AFTER the caller had switched c->deep to the eight-iteration shape,
+        // so the depth trial never refreshed rows 7-8 a six-row schedule had left stale — timing only, the state is re-initialised)
+        const bool deeper = halo_rows(c) > frame_rows;
+        frame_rows = halo_rows(c);
+        if (deeper) {      // the schedule on trial refreshes a deeper ghost frame: fill it before its first launch reads it
             rc = join_comm(c);
             if (rc) return rc;
             rc = exchange_rccl<T>(c, c->cur, c->stream);
@@ -306,8 +313,9 @@ int tune_strip_schedule(lbm_ctx* c) {
         } else {
             c->deep = 1; c->fuse = deep_depth(1);
         }
-        snprintf(c->plan_opts, sizeof(c->plan_opts), "%s", plan_option_string(c->layout, c->variant, c->use_nt, c->alternate, c->pair_ty, c->xcd, c->fuse, c->deep, c->use_ntl).c_str());
+        snprintf(c->plan_opts, sizeof(c->plan_opts), "%s", plan_option_string(c->layout, c->use_nt, c->alternate, c->pair_ty, c->xcd, c->fuse, c->deep, c->use_ntl).c_str());
     }
+    guard.armed = false;
     c->trailing_pair = keep_tp;
     if (!res.empty()) {
         c->overlap = res[0].o; c->deep_halo = res[0].d;

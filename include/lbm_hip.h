@@ -29,6 +29,8 @@ extern "C" {
 #define LBM_ERR_HIP      -2   /* HIP runtime error or no device */
 #define LBM_ERR_COMM     -3   /* RCCL error / communicator not initialised */
 #define LBM_ERR_ALLOC    -4
+#define LBM_ERR_TIMEOUT  -5   /* a host-side wait of the library ran into its bound (option "wait_timeout_ms", LBM_WAIT_TIMEOUT_MS): the
+                               * text names who was waited for and where; a group that timed out is unusable, destroy it */
 
 #define LBM_PRECISION_F64 0
 #define LBM_PRECISION_F32 1   /* build-only variant; the reference has no fp32 path */
@@ -164,7 +166,7 @@ int  lbm_load_state(lbm_ctx* c, const char* path);
 
 /* Tuning/diagnostics (not part of the reference surface). Keys, all to be set before lbm_initialise:
  *   "tune" 1|0    time the candidate plans at lbm_initialise and keep the fastest (default 1); with 0 the plan is
- *                 "layout" 0 planar|1 row-interleaved, "variant" (accepted and ignored since round 4: the 16-B-per-lane kernel it selected is retired),
+ *                 "layout" 0 planar|1 row-interleaved,
  *                 "nt" non-temporal stores, "ntl" non-temporal level-1 loads of the register kernel ("deep" 6 / 7),
  *                 "alternate" alternate the row walk direction per launch,
  *                 "fuse" 1|2|3|4 iterations fused per launch through LDS (k_step2_tile / k_step3_tile / k_step4_tile, the
@@ -205,7 +207,7 @@ const char* lbm_kernel_name(const lbm_ctx* c);
 /* The plan lbm_initialise settled on (layout / kernel / store policy / traversal), for logs; where it was measured, with the
  * finalists' times (median of three windows each) so that the margin of the choice is visible. */
 const char* lbm_plan(const lbm_ctx* c);
-/* The same plan as lbm_set_option pairs, "layout=1 variant=1 nt=0 alternate=1 pair_ty=12 xcd=1 deep=7": set
+/* The same plan as lbm_set_option pairs, "layout=1 nt=0 alternate=1 pair_ty=12 xcd=1 deep=7": set
  * on a fresh context together with "tune" 0 they reproduce the plan in another process (bench.py's counter passes run
  * the benchmarked plan in a child process under rocprofv3). No reference counterpart. */
 const char* lbm_plan_options(const lbm_ctx* c);
@@ -221,6 +223,18 @@ int lbm_debug_strip_pins(const int* per_rank5, int nranks, int* agreed5);
 /* Test hook, callable without a device: the candidate plans lbm_initialise would time on a whole-domain context of this grid
  * (csrc/lbm_plan.hpp), one per line: "name|lbm_set_option pairs|dominant kernel|iterations per launch". */
 int lbm_debug_plan_candidates(int nx, int ny, int precision, int arith, int num_cus, char* out, int cap);
+/* Test hook, callable without a device: a DRY RUN of the launch choreography of a strip run and its check (csrc/lbm_choreo.inc.hpp). The
+ * functions that issue a launch group (plan_launch, issue_before, the exchanges, issue_after) run on contexts without a device and
+ * record every kernel (with the rows it writes and, through its depth, reads), event record, cross-stream wait, copy, send and receive;
+ * the record is replayed with vector clocks. Returns the number of violations — RACE: two accesses to the same row of the same buffer, at
+ * least one of them a write, that no event orders; STALE: a launch (or the force kernel) reads a row that does not hold the iteration it
+ * needs — or < 0; `out` receives their description (and, with dump != 0, every recorded operation). What it replaces: the ordering the
+ * reference gets from MPI_Waitall before unpack_received_data (LBMGrid.h:278-283).
+ * bounds2 = nstrips x {y_start, rows}; transport 0 in-process group with peer copies, 1 in-process group over RCCL, 2 ONE strip as a rank
+ * of a multi-process RCCL run (its faces follow from y_start / rows / ny), 3 ONE strip exchanging with itself (loopback copies);
+ * options = "key=value ..." as for lbm_set_option (the plan must be pinned: nothing is measured); calls2 = ncalls x {nsteps, output_frequency}. */
+int lbm_debug_choreography(int nx, int ny, const int* bounds2, int nstrips, int precision, int transport, const char* options,
+                           const int* calls2, int ncalls, int dump, char* out, int cap);
 /* SHA-256 (16 hex digits) of the sources this binary was compiled from (csrc/ and this header); build.py rebuilds
  * when it differs from the tree, bench.py prints it. */
 const char* lbm_build_id(void);

@@ -45,7 +45,7 @@ class FakeContext:
     def graph_replays(self): return 0
     def kernel_name(self): return "k_stepc_col<double,4,8,6,false,1>"
     def plan(self): return "row-interleaved/6-step 64x32 in registers/xcd (test double)"
-    def plan_options(self): return dict(layout=1, variant=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=7)
+    def plan_options(self): return dict(layout=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=7)
     def strip_schedule(self): return "overlap=1 deep_halo=0 (test double); 1783296 B per face and exchange = 297216 B per face and iteration (6 iterations per exchange)"
 
     def populations(self, which):

@@ -52,7 +52,7 @@ def main():
     else:
         pairs = backend.endswith("-pair")
         backend = backend.replace("-pair", "")
-        opts = dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=8, xcd=1, trailing_pair=1) if pairs else None
+        opts = dict(tune=0, layout=1, nt=1, fuse=3, pair_ty=8, xcd=1, trailing_pair=1) if pairs else None
         ctx = lbm.Context(nx, ny, y_start=y0, local_ny=nloc, device=0, options=opts, **kw)
         halo = lbm.GlooHalo(rank, world, (ctx.HALO_ROWS, 9, nx))
         if backend == "hip-rccl":

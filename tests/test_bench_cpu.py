@@ -62,7 +62,9 @@ def test_measured_traffic_lookup_and_labels():
     assert t is None and "no counter pass" in note
     # nearest sibling instead of nothing: a kernel the table does not hold, same family / element type / depth
     t, note = b.measured_traffic(16384, 4096, "f32", "k_stepc_col<float,4,8,5,false,7>")
-    assert t and t["approximate"] and "sibling" in note and b.kernel_family(t["kernel"]) == ("k_stepc_col", "float", 5)
+    assert t and t["approximate"] and "sibling" in note and b.kernel_family(t["kernel"]) == ("k_stepc_col", "float", 5, 4, 8)
+    # ... but never another region shape: the tall 64x48 regions (twelve waves) fetch 15 % less than the 64x32 ones
+    assert b.kernel_family("k_stepc_col<float,4,12,7,false,1>") != b.kernel_family("k_stepc_col<float,4,8,7,false,1>")
     assert b.plan_depth_of("k_stepc_col<double,4,8,6,true,1>") == 6 and b.plan_depth_of("k_stepd_tile<double,32,32,8,1>") == 8
     assert b.plan_depth_of("k_step3_tile<double,12,1024,1>") == 3 and b.plan_depth_of("k_step_site<double,0,true,1>") == 1
     assert b.CONFIGS[(4096, 1024, "f64", 200.0)] == "configs[2]" and b.CONFIGS[(1024, 256, "f64", 100.0)] == "configs[1]"
@@ -103,7 +105,7 @@ def test_roofline_object_from_a_committed_pass():
     class Ctx:
         def kernel_name(self): return "k_stepc_col<double,4,8,6,false,1>"
         def plan(self): return "row-interleaved/6-step 64x32 in registers/xcd (fastest of 27 measured, 26.9 us/iteration)"
-        def plan_options(self): return dict(layout=1, variant=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=7)
+        def plan_options(self): return dict(layout=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=7)
     r = b.roofline_of(Lbm, Ctx(), 4096, 1024, "f64", 0.160, 1000, 6000, 6000, live=False)
     assert r["iterations_per_launch"] == 6.0 and r["algorithmic_bytes_per_launch"] == 4096 * 1024 * 144 * 6
     assert abs(r["frac"] - 4096 * 1024 * 144 * 6 / 0.160e-3 / 8e12) < 1e-3 and r["frac"] == r["frac_144B"] > 2.0

@@ -7,11 +7,12 @@ Tolerance (north_star): rho and u within 1e-10 relative (L-inf / L-inf; velocity
 max|u|), Fx/Fy within 1e-10 relative. Observed on MI355X: see DESIGN.md §parity.
 """
 import importlib
+import os
 
 import numpy as np
 import pytest
 
-from tests.helpers import golden_params, linf_rel, load_golden, macro_errors, record
+from tests.helpers import ROOT, golden_params, linf_rel, load_golden, macro_errors, record
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -29,50 +30,50 @@ def lbm():
 # the parity tests run each of them explicitly. None = the measured plan (tune=1, the default).
 PLANS = {
     "auto": None,
-    "planar-vec-alt": dict(tune=0, layout=0, variant=0, nt=0, alternate=1),
-    "planar-site": dict(tune=0, layout=0, variant=1, nt=0, alternate=0),
-    "rowil-site-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0),
-    "rowil-vec-nt-alt": dict(tune=0, layout=1, variant=0, nt=1, alternate=1),
+    "planar-vec-alt": dict(tune=0, layout=0, nt=0, alternate=1),
+    "planar-site": dict(tune=0, layout=0, nt=0, alternate=0),
+    "rowil-site-nt": dict(tune=0, layout=1, nt=1, alternate=0),
+    "rowil-vec-nt-alt": dict(tune=0, layout=1, nt=1, alternate=1),
     # two iterations fused per launch through LDS (k_step2_tile; partial tiles cover any nx)
-    "planar-pair8-nt": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, pair=1, pair_ty=8),
-    "rowil-pair12-alt": dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair=1, pair_ty=12, xcd=1),
+    "planar-pair8-nt": dict(tune=0, layout=0, nt=1, alternate=0, pair=1, pair_ty=8),
+    "rowil-pair12-alt": dict(tune=0, layout=1, nt=0, alternate=1, pair=1, pair_ty=12, xcd=1),
     # three iterations fused per launch (k_step3_tile)
-    "planar-fuse3-8": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=3, pair_ty=8),
-    "rowil-fuse3-12-nt-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1),
+    "planar-fuse3-8": dict(tune=0, layout=0, nt=0, alternate=1, fuse=3, pair_ty=8),
+    "rowil-fuse3-12-nt-xcd": dict(tune=0, layout=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1),
     # four iterations fused per launch (k_step4_tile, 64x8 tiles; strips fall back to three)
-    "rowil-fuse4-nt-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1),
-    "planar-fuse4-alt": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=4, pair_ty=8, xcd=0),
+    "rowil-fuse4-nt-xcd": dict(tune=0, layout=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1),
+    "planar-fuse4-alt": dict(tune=0, layout=0, nt=0, alternate=1, fuse=4, pair_ty=8, xcd=0),
     # six / seven / eight iterations per launch on an LDS-filling tile (k_stepd_tile; what a small grid's measurement picks);
     # calls whose length is no multiple of the depth finish with the four-/three-/two-iteration tile kernels
-    "rowil-deep6-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=1),
-    "planar-deep7-alt": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, pair_ty=8, xcd=0, deep=2),
-    "rowil-deep8-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=3),
+    "rowil-deep6-nt": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=1),
+    "planar-deep7-alt": dict(tune=0, layout=0, nt=0, alternate=1, pair_ty=8, xcd=0, deep=2),
+    "rowil-deep8-nt": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=3),
     # five / six iterations per launch with the lattice held in registers (k_stepc_col: 64x32 regions, DPP x-shifts, six LDS
     # values per wave and level; round 3's production kernel — what a large grid's measurement and the strip rule pick)
-    "rowil-col5-nt": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=6),
-    "planar-col6-alt": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, pair_ty=8, xcd=1, deep=7),
+    "rowil-col5-nt": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=6),
+    "planar-col6-alt": dict(tune=0, layout=0, nt=0, alternate=1, pair_ty=8, xcd=1, deep=7),
     # contracted collision arithmetic (option "arith" 1: FMA + one reciprocal, what the reference's -ffast-math -mfma build
     # permits): not bit-identical to the strict oracle, held to the north-star tolerance 1e-10 like every other plan
     "fast-auto": dict(arith=1),
-    "fast-site": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1, arith=1),
-    "fast-vec-alt": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=1, arith=1),
-    "fast-rowil-fuse3-12-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
-    "fast-planar-pair8": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, pair=1, pair_ty=8, arith=1),
-    "fast-rowil-fuse4-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
-    "fast-rowil-deep7": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=2, arith=1),
-    "fast-planar-deep8": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=3, arith=1),
-    "fast-rowil-col6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
-    "fast-planar-col5": dict(tune=0, layout=0, variant=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=6, arith=1),
+    "fast-site": dict(tune=0, layout=1, nt=1, alternate=0, fuse=1, arith=1),
+    "fast-vec-alt": dict(tune=0, layout=0, nt=0, alternate=1, fuse=1, arith=1),
+    "fast-rowil-fuse3-12-xcd": dict(tune=0, layout=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
+    "fast-planar-pair8": dict(tune=0, layout=0, nt=0, alternate=1, pair=1, pair_ty=8, arith=1),
+    "fast-rowil-fuse4-xcd": dict(tune=0, layout=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
+    "fast-rowil-deep7": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=2, arith=1),
+    "fast-planar-deep8": dict(tune=0, layout=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=3, arith=1),
+    "fast-rowil-col6": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
+    "fast-planar-col5": dict(tune=0, layout=0, nt=0, alternate=0, pair_ty=8, xcd=1, deep=6, arith=1),
     # non-temporal level-1 loads in the register kernel (round 4: a store-policy-like choice of the plan measurement)
-    "rowil-col6-ntl-alt": dict(tune=0, layout=1, variant=1, nt=0, ntl=1, alternate=1, pair_ty=12, xcd=1, deep=7),
-    "fast-rowil-col6-ntl": dict(tune=0, layout=1, variant=1, nt=0, ntl=1, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
+    "rowil-col6-ntl-alt": dict(tune=0, layout=1, nt=0, ntl=1, alternate=1, pair_ty=12, xcd=1, deep=7),
+    "fast-rowil-col6-ntl": dict(tune=0, layout=1, nt=0, ntl=1, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
     # seven iterations as the plan's own depth (round 4: what the largest grids' measurement picks; strips exchange seven rows)
-    "rowil-col7-alt": dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair_ty=12, xcd=1, deep=9),
-    "fast-rowil-col7": dict(tune=0, layout=1, variant=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=9, arith=1),
+    "rowil-col7-alt": dict(tune=0, layout=1, nt=0, alternate=1, pair_ty=12, xcd=1, deep=9),
+    "fast-rowil-col7": dict(tune=0, layout=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=9, arith=1),
 }
 FAST = [k for k, v in PLANS.items() if v and v.get("arith")]
 # fp32 contexts only (round 4): seven iterations per launch on TALL 64x48 regions in registers (contracted: twelve waves x four rows; strict: eight x six)
-TALL_F32 = dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair_ty=12, xcd=1, deep=8)
+TALL_F32 = dict(tune=0, layout=1, nt=0, alternate=1, pair_ty=12, xcd=1, deep=8)
 
 
 def strict(plan):
@@ -364,7 +365,7 @@ def test_overlap_choreography_with_loopback_halo(lbm, pair):
     out = []
     # deep_halo=0: one exchange after every launch; deep_halo=1: one per two launches (the first one extended)
     for overlap, deep in ((0, 0), (0, 1), (1, 1), (1, 0), (2, 1), (2, 0)):
-        with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, fuse=pair, pair_ty=12, xcd=1,
+        with lbm.Context(nx, ny, options=dict(tune=0, layout=1, nt=1, fuse=pair, pair_ty=12, xcd=1,
                                               loopback=1, overlap=overlap, deep_halo=deep), **kw) as ctx:
             ctx.initialise()
             ctx.step(steps, 50)
@@ -517,6 +518,84 @@ def test_a_failing_strip_is_an_error_not_a_hang(lbm, threads):
             g.step(30, 0)
 
 
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("point", [0, 1, 2])
+def test_a_strip_that_fails_between_two_rendezvous_is_an_error_not_a_hang(lbm, point):
+    """a member whose runtime call fails BETWEEN two rendezvous of the group's threads (injected: strip 1, third
+    launch, before the first / second / third rendezvous) must not skip an arrival — every error goes through report() and the
+    whole group leaves at the next rendezvous. The call returns the strip's error, the pool's threads are parked again, and the
+    group, re-initialised, reproduces the one-domain run bit for bit."""
+    nx, ny, steps = 256, 120, 31
+    kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
+    with lbm.Context(nx, ny, options=PLANS["rowil-site-nt"], **kw) as whole:
+        whole.initialise()
+        whole.step(steps, 0)
+        w_fn = whole.populations("f_next")
+    with lbm.Group(nx, ny, 3, options=PLANS["rowil-fuse3-12-nt-xcd"], **kw) as g:
+        g.initialise()
+        g.ctxs[1].set_option("debug_fault_point", point)
+        g.ctxs[1].set_option("debug_fault_launch", 2)
+        with pytest.raises(lbm.LbmError, match=f"injected fault: strip 1, launch 2, point {point}"):
+            g.step(steps, 0)
+        g.initialise()
+        g.step(steps, 0)
+        assert g.first_unstable_step() == -1 and np.array_equal(g.populations("f_next"), w_fn)
+
+
+@pytest.mark.timeout(120)
+def test_a_stalled_strip_turns_into_a_timeout_that_names_it(lbm):
+    """Every host-side wait of a group is bounded (round 5; rounds 3-4 waited on a std::barrier and an untimed condition
+    variable): a strip that does not reach a rendezvous within "wait_timeout_ms" (injected: strip 2 sleeps 1.5 s between the first
+    and the second rendezvous of its second launch) makes lbm_group_step return LBM_ERR_TIMEOUT within the bound, naming the strip and
+    where it was last seen; the group refuses further work and its teardown waits for the straggler instead of freeing under it."""
+    import time
+    nx, ny = 256, 120
+    kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
+    with lbm.Group(nx, ny, 3, options=dict(PLANS["rowil-fuse3-12-nt-xcd"], wait_timeout_ms=250), **kw) as g:
+        g.initialise()
+        for key, v in (("debug_fault_point", 1), ("debug_fault_stall_ms", 1500), ("debug_fault_launch", 1)):
+            g.ctxs[2].set_option(key, v)
+        t0 = time.time()
+        with pytest.raises(lbm.LbmError, match=r"lbm_hip error -5: strip [01] waited 250 ms at rendezvous 2 of launch 1 of this call for: strip 2 \(last seen at rendezvous 1 of launch 1\)"):
+            g.step(30, 0)
+        assert time.time() - t0 < 1.2
+        with pytest.raises(lbm.LbmError, match="timed out earlier"):
+            g.step(1, 0)
+
+
+@pytest.mark.timeout(120)
+def test_lbm_sync_is_bounded(lbm):
+    """lbm_sync polls the streams instead of blocking in hipStreamSynchronize: with a bound far below the queued work (a few
+    thousand iterations of the headline grid) it returns LBM_ERR_TIMEOUT naming the stream and the iteration the queue reaches;
+    with the default bound the same call then drains the queue."""
+    with lbm.Context(4096, 1024, inlet_velocity=0.0651, options=dict(PLANS["fast-rowil-col6"], trailing_pair=1)) as c:
+        c.initialise()
+        c.sync()
+        c.set_option("wait_timeout_ms", 2)
+        c.step(3000, 0)
+        with pytest.raises(lbm.LbmError, match=r"lbm_hip error -5: compute stream of the strip of rows 0..1024 on device 0 still busy after 2 ms \(work queued up to iteration 3000\)"):
+            c.sync()
+        c.set_option("wait_timeout_ms", 0)
+        c.sync()
+        assert c.steps_done == 3000 and c.first_unstable_step() == -1
+
+
+@pytest.mark.timeout(180)
+def test_the_trace_file_names_the_last_thing_started(tmp_path):
+    """LBM_TRACE=<file>: one flushed line per coarse event (initialise / step / destroy, begin and end), so that a run killed for
+    being silent leaves its last started call on record (a seven-minute stall left an empty log)."""
+    import subprocess
+    import sys
+    trace = tmp_path / "trace.txt"
+    code = (f"import importlib, sys; sys.path.insert(0, {ROOT!r}); lbm = importlib.import_module({PKG!r})\n"
+            "with lbm.Context(256, 64) as c:\n    c.initialise(); c.step(7, 0); c.sync()\n")
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LBM_TRACE=str(trace)), timeout=170)
+    lines = trace.read_text().splitlines()
+    tags = [ln.split()[5] for ln in lines]
+    assert tags[0] == "initialise" and "step" in tags and tags[-1] == "destroy" and lines[-1].endswith("end")
+    assert any("t=0 +7 begin" in ln for ln in lines)
+
+
 def test_group_checkpoint_restart(lbm, tmp_path):
     """Per-strip checkpoints of a group, restored into a fresh group (lbm_group_refresh_halos), continue bit-exactly."""
     nx, ny = 256, 96
@@ -655,7 +734,7 @@ def test_rccl_calls_on_a_one_rank_communicator(lbm):
     kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
     out = []
     for loopback, overlap in ((1, 0), (2, 1), (2, 0), (2, 2)):
-        with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1,
+        with lbm.Context(nx, ny, options=dict(tune=0, layout=1, nt=1, fuse=3, pair_ty=12, xcd=1,
                                               loopback=loopback, overlap=overlap), **kw) as ctx:
             if loopback == 2:
                 ctx.comm_init(0, 1, ctx.comm_unique_id())
@@ -678,7 +757,7 @@ def test_launch_groups_replayed_from_a_graph_match_the_eager_path(lbm, loopback,
     stretch (the kernels' iteration numbers are relative to a device word the graph advances) — with device copies and with
     RCCL send/recv to self as the transport, overlapped and serialised."""
     nx, ny = 512, 160
-    base = dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, loopback=loopback, overlap=overlap)
+    base = dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, loopback=loopback, overlap=overlap)
     for kw, steps, of in ((dict(inlet_velocity=0.05, cylinder_radius=0.1), 437, 150),
                           (dict(inlet_velocity=0.05, cylinder_radius=0.1, tau=0.5006), 700, 0)):        # the second one blows up
         out = []
@@ -708,7 +787,7 @@ def test_strip_schedule_is_measured_and_result_invariant(lbm):
     nx, ny, steps = 1024, 128, 151
     kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
     out = []
-    for opts in (dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, loopback=2, overlap=0, deep_halo=0),
+    for opts in (dict(tune=0, layout=1, nt=1, fuse=3, pair_ty=12, xcd=1, loopback=2, overlap=0, deep_halo=0),
                  dict(loopback=2), dict(loopback=2, overlap=1), dict(loopback=2, arith=0, deep_halo=1)):
         with lbm.Context(nx, ny, options=opts, **kw) as ctx:
             ctx.comm_init(0, 1, ctx.comm_unique_id())
@@ -781,7 +860,7 @@ def test_reinitialise_and_destroy_release_device_memory(lbm):
     with lbm.Context(64, 32) as warm:      # the runtime's one-time allocations (code objects, queues: ~170 MB) happen here
         warm.initialise()
     # ... and the queue's scratch memory (~29 MB, kept by the runtime): the strict register kernel spills 12 VGPRs
-    with lbm.Context(256, 64, options=dict(tune=0, layout=1, variant=1, nt=1, xcd=1, deep=7)) as warm:
+    with lbm.Context(256, 64, options=dict(tune=0, layout=1, nt=1, xcd=1, deep=7)) as warm:
         warm.initialise()
         warm.step(12, 0)
     free0, _ = lbm.device_memory(0)
@@ -810,7 +889,7 @@ def test_graphs_and_group_threads_are_released(lbm):
     allocations — graph pools, scratch, per-thread state — are taken by two warm-up rounds: measured, they stop growing there)."""
     def threads():
         return int(next(l for l in open("/proc/self/status") if l.startswith("Threads:")).split()[1])
-    base = dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7)
+    base = dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7)
 
     def round_(k):
         with lbm.Context(512, 160, inlet_velocity=0.05, options=dict(base, loopback=1, overlap=k % 2)) as ctx:

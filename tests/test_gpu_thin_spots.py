@@ -186,7 +186,7 @@ def test_deep_plans_in_pairs_over_a_twelve_row_halo(lbm, precision, ny, bounds, 
     nx, steps, of = 512, 333, 70
     kw = dict(inlet_velocity=0.05, cylinder_radius=0.1, precision=precision)
     ftol = 1e-13 if precision == "f64" else 1e-5        # partial force sums are added in a different order
-    with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1), **kw) as whole:
+    with lbm.Context(nx, ny, options=dict(tune=0, layout=1, nt=1, alternate=0, fuse=1), **kw) as whole:
         whole.initialise()
         whole.step(steps, of)
         w_fn, w_log = whole.populations("f_next"), whole.drain_force_log()
@@ -212,7 +212,7 @@ def test_deep_pairs_on_one_strip_with_the_rccl_transport(lbm, loopback):
     launches over a twelve-row halo == one exchange of six rows per launch, bit for bit, overlapped and serialised; and a run
     that blows up reports the same first unstable iteration."""
     nx, ny = 512, 256
-    base = dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, loopback=loopback)
+    base = dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, loopback=loopback)
     for kw, steps, of in ((dict(inlet_velocity=0.05, cylinder_radius=0.1), 437, 150),
                           (dict(inlet_velocity=0.05, cylinder_radius=0.1, tau=0.5006), 700, 0)):        # the second one blows up
         out = []
@@ -246,8 +246,8 @@ def test_seven_and_eight_iteration_lds_shapes_on_strips(lbm, deep, precision):
     nx, ny, steps, of = 512, 300, 333, 70
     kw = dict(inlet_velocity=0.05, cylinder_radius=0.1, precision=precision)
     ftol = 1e-13 if precision == "f64" else 1e-5
-    plan = dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=deep)
-    with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1), **kw) as whole:
+    plan = dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=deep)
+    with lbm.Context(nx, ny, options=dict(tune=0, layout=1, nt=1, alternate=0, fuse=1), **kw) as whole:
         whole.initialise()
         whole.step(steps, of)
         w_fn, w_log = whole.populations("f_next"), whole.drain_force_log()
@@ -289,8 +289,8 @@ def test_tall_fp32_regions_in_registers(lbm, arith):
     with pytest.raises(lbm.LbmError, match="fp32 only"):
         lbm.Context(256, 64, precision="f64", options=dict(tune=0, deep=8))
     shape = "4,12" if arith else "6,8"      # rows per thread, waves per block
-    site = dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1, arith=arith)
-    tall = dict(tune=0, layout=1, variant=1, nt=0, alternate=1, pair_ty=12, xcd=1, deep=8, arith=arith)
+    site = dict(tune=0, layout=1, nt=1, alternate=0, fuse=1, arith=arith)
+    tall = dict(tune=0, layout=1, nt=0, alternate=1, pair_ty=12, xcd=1, deep=8, arith=arith)
     for (nx, ny, steps, of, kw) in ((300, 170, 333, 45, dict(inlet_velocity=0.05, cylinder_radius=0.1)),
                                     (1024, 256, 200, 0, dict(inlet_velocity=0.1)),
                                     (190, 140, 150, 31, dict(inlet_velocity=0.04, cylinder_x=0.02, cylinder_radius=0.12))):
@@ -344,3 +344,78 @@ def test_tall_fp32_regions_in_registers(lbm, arith):
             assert (ctx.graph_replays() > 0) == (graph == 1), ctx.strip_schedule()
     for other in out[1:]:
         assert np.array_equal(out[0][0], other[0]) and out[0][1] == other[1]
+
+
+def test_the_fp32_kernel_of_the_bench_line_at_its_own_size_and_mode(lbm):
+    """the driver's fp32 line (BASELINE.json configs[4] on one GPU) reports k_stepc_col<float,4,12,7,false,1> —
+    CONTRACTED arithmetic, twelve waves x four rows, seven iterations per launch — at 16384x4096, and until round 5 every full-size
+    fp32 test ran strict arithmetic. Here: that kernel (pinned, name asserted; and whatever options=dict(arith=1) measures, which
+    must agree with it bit for bit) for 300 iterations against this library's fp64 CONTRACTED path on the same grid at the stated
+    2e-5 (rho) / 2e-4 (u) / 1e-4 (forces), and bit-equal to one contracted k_step_site launch per iteration on the same grid
+    (300 iterations, two force outputs; and a 21-iteration call = 7+7+6+1). What it must reproduce: collision_step,
+    /root/reference/include/LBMSolver.h:84-126, in single precision (the reference has no fp32 path)."""
+    nx, ny, steps = 16384, 4096, 300
+    kw = dict(inlet_velocity=0.01627604, precision="f32")
+    tall = dict(tune=0, layout=1, nt=0, alternate=1, pair_ty=12, xcd=1, deep=8, arith=1)
+    site = dict(tune=0, layout=1, nt=1, alternate=0, fuse=1, arith=1)
+
+    def run(options, n, of):
+        with lbm.Context(nx, ny, options=options, **kw) as ctx:
+            assert ctx.initialise() == 130721
+            ctx.step(n, of)
+            assert ctx.first_unstable_step() == -1
+            return ctx.macros(), ctx.drain_force_log(), ctx.plan(), ctx.kernel_name().replace(" ", "")
+    m_tall, log_tall, _, k_tall = run(tall, steps, 150)
+    assert k_tall == "k_stepc_col<float,4,12,7,false,1>", k_tall
+    m_auto, log_auto, plan_auto, k_auto = run(dict(arith=1), steps, 150)
+    print("C5 contracted, measured plan:", plan_auto, "|", k_auto)
+    assert k_auto.startswith("k_stepc_col<float,") and k_auto.endswith(",1>"), k_auto
+    for a, b in zip(m_tall, m_auto):
+        assert np.array_equal(a, b)
+    assert log_auto == log_tall
+    del m_auto
+    m_site, log_site, _, k_site = run(site, steps, 150)
+    assert k_site == "k_step_site<float,0,true,1>", k_site
+    for a, b in zip(m_tall, m_site):
+        assert np.array_equal(a, b)
+    assert log_site == log_tall
+    del m_site
+    (a21, l21, _, _), (b21, m21, _, _) = run(tall, 21, 0), run(site, 21, 0)
+    for a, b in zip(a21, b21):
+        assert np.array_equal(a, b)
+    del a21, b21
+    with lbm.Context(nx, ny, inlet_velocity=0.01627604, precision="f64", options=dict(arith=1)) as c64:
+        assert c64.initialise() == 130721
+        c64.step(steps, 150)
+        assert c64.first_unstable_step() == -1
+        m64, log64 = c64.macros(), c64.drain_force_log()
+    er, eu = macro_errors(*m_tall, *m64)
+    ef = max(max(abs(a[1] - b[1]), abs(a[2] - b[2])) / abs(b[1]) for a, b in zip(log_tall, log64))
+    record("c5_16384x4096_f32_contracted_tall_vs_hip_f64_contracted_300", rho=er, u=eu, force=ef, kernel=k_tall, measured_plan=plan_auto)
+    print(f"C5 fp32 contracted (tall regions) vs fp64 contracted (HIP) x {steps}: rho {er:.3e}, u {eu:.3e}, force {ef:.3e}")
+    assert er < 2e-5 and eu < 2e-4 and ef < 1e-4, (er, eu, ef)
+
+
+def test_fp32_contracted_plans_agree_bit_for_bit_at_1024x256(lbm):
+    """The link VERDICT r04 (weak 1a) found unasserted: in fp32 CONTRACTED arithmetic plan-independence was held tall <-> site only,
+    while the oracle bound (2e-4 after 1000 iterations, tests/test_gpu_parity.py) is asserted on the MEASURED plan. Here, at
+    1024x256 x 1000: measured plan == one launch per iteration == tall regions == 64x32 regions == LDS tiles, populations bit for bit."""
+    nx, ny, steps = 1024, 256, 1000
+    kw = dict(inlet_velocity=0.13020833, precision="f32")
+    plans = {"auto": dict(arith=1), "site": dict(tune=0, layout=1, nt=1, alternate=0, fuse=1, arith=1),
+             "tall": dict(tune=0, layout=1, nt=0, alternate=1, pair_ty=12, xcd=1, deep=8, arith=1),
+             "col6": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
+             "lds8": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=3, arith=1),
+             "tile3": dict(tune=0, layout=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1)}
+    out = {}
+    for name, options in plans.items():
+        with lbm.Context(nx, ny, options=options, **kw) as ctx:
+            assert ctx.initialise() == 441
+            ctx.step(steps, 0)
+            assert ctx.first_unstable_step() == -1
+            out[name] = (ctx.populations("f_next"), ctx.kernel_name().replace(" ", ""))
+    assert out["tall"][1] == "k_stepc_col<float,4,12,7,false,1>" and out["site"][1] == "k_step_site<float,0,true,1>"
+    print("fp32 contracted 1024x256, measured plan:", out["auto"][1])
+    for name, (fn, kernel) in out.items():
+        assert np.array_equal(fn, out["site"][0]), (name, kernel)
+

@@ -4,9 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 lbm = importlib.import_module("highperformancecomputing-latticeboltzmannmethod_amd")
 nx, ny, steps, of = 512, 200, 333, 70
 kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
-with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1), **kw) as whole:
+with lbm.Context(nx, ny, options=dict(tune=0, layout=1, nt=1, alternate=0, fuse=1), **kw) as whole:
     whole.initialise(); whole.step(steps, of); w_fn = whole.populations("f_next")
-base = dict(tune=0, layout=1, variant=1, alternate=0, pair_ty=12, xcd=1, deep=1)
+base = dict(tune=0, layout=1, alternate=0, pair_ty=12, xcd=1, deep=1)
 for name, extra in (("tuned", dict(deep_halo=2)), ("nt1", dict(base, nt=1, deep_halo=2)), ("nt1 nothr", dict(base, nt=1, deep_halo=2, group_threads=0)),
                     ("nt1 ser", dict(base, nt=1, deep_halo=2, overlap=0)), ("nt1 single", dict(base, nt=1, deep_halo=1)),
                     ("nt1 of0", dict(base, nt=1, deep_halo=2))):

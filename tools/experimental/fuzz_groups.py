@@ -33,14 +33,14 @@ def main():
         bounds = [(a, b - a) for a, b in zip(edges, edges[1:])]
         calls = [(int(rng.integers(20, 300)), int(rng.choice([0, 31, 50, 70, 140]))) for _ in range(int(rng.integers(1, 3)))]
         deep = int(rng.choice([0, 1, 2, 3, 6, 7, 9] + ([8] if precision == "f32" else [])))
-        opts = dict(tune=0, layout=1, variant=1, nt=int(rng.integers(0, 2)) if deep != 8 else 0, ntl=int(rng.integers(0, 2)), alternate=0, pair_ty=12, xcd=1,
+        opts = dict(tune=0, layout=1, nt=int(rng.integers(0, 2)) if deep != 8 else 0, ntl=int(rng.integers(0, 2)), alternate=0, pair_ty=12, xcd=1,
                     arith=arith, overlap=int(rng.integers(0, 3)), deep_halo=int(rng.integers(0, 3)), group_threads=int(rng.integers(0, 2)))
         if deep:
             opts["deep"] = deep
         else:
             opts["fuse"] = int(rng.integers(1, 4))
         try:
-            with lbm.Context(nx, ny, options=dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1, arith=arith), **kw) as w:
+            with lbm.Context(nx, ny, options=dict(tune=0, layout=1, nt=1, alternate=0, fuse=1, arith=arith), **kw) as w:
                 w.initialise()
                 for steps, of in calls:
                     w.step(steps, of)

@@ -38,7 +38,7 @@ def main():
         arith = int(rng.integers(0, 2))
         kw = dict(inlet_velocity=float(rng.uniform(0.01, 0.08)), tau=float(rng.uniform(0.56, 1.0)), cylinder_radius=float(rng.choice([0.0, 0.08, 0.15])), precision=precision)
         calls = [(int(rng.integers(1, 200)), int(rng.choice([0, 7, 31, 64, 160]))) for _ in range(int(rng.integers(1, 4)))]
-        base = dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=1, arith=arith, loopback=1, overlap=0, deep_halo=1, graph=0)
+        base = dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=1, arith=arith, loopback=1, overlap=0, deep_halo=1, graph=0)
         deep = int(rng.choice([1, 2, 3, 6, 7, 9] + ([8] if precision == "f32" else [])))
         opts = dict(base, deep=deep, nt=int(rng.integers(0, 2)) if deep != 8 else 0, ntl=int(rng.integers(0, 2)), loopback=int(rng.integers(1, 3)),
                     overlap=int(rng.integers(0, 3)), deep_halo=int(rng.integers(0, 3)), graph=int(rng.integers(0, 2)), trailing_pair=int(rng.integers(0, 2)))

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 lbm = importlib.import_module("highperformancecomputing-latticeboltzmannmethod_amd")
 for rows in [int(v) for v in sys.argv[1:]] or (512, 256):
     out = [f"rows={rows}:"]
-    base = dict(tune=0, layout=1, variant=1, pair_ty=12, xcd=1, arith=1, trailing_pair=1, loopback=2)
+    base = dict(tune=0, layout=1, pair_ty=12, xcd=1, arith=1, trailing_pair=1, loopback=2)
     cases = [("TUNED", dict(arith=1, trailing_pair=1, loopback=2))]
     for deep, label in ((7, "six"), (9, "seven")):
         for nt, ntl in ((0, 0), (1, 0), (0, 1)):

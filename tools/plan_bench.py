@@ -17,35 +17,35 @@ lbm = importlib.import_module("highperformancecomputing-latticeboltzmannmethod_a
 
 PLANS = {
     "auto": None,
-    "site": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1),
-    "vec": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=1),
-    "tile2": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=2, pair_ty=12, xcd=0),
-    "tile3": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=0),
-    "tile3-rowil": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1),
-    "fast-tile3": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=0, arith=1),
-    "fast-tile3-rowil-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
-    "fast-tile3-rowil-xcd-8": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=8, xcd=1, arith=1),
-    "tile3-rowil-xcd": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1),
-    "ft3-nt0-alt0": dict(tune=0, layout=1, variant=1, nt=0, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
-    "ft3-nt0-alt1": dict(tune=0, layout=1, variant=1, nt=0, alternate=1, fuse=3, pair_ty=12, xcd=1, arith=1),
-    "ft3-nt1-alt1": dict(tune=0, layout=1, variant=1, nt=1, alternate=1, fuse=3, pair_ty=12, xcd=1, arith=1),
-    "ft3-planar-xcd": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
-    "ft3-planar-xcd-alt": dict(tune=0, layout=0, variant=0, nt=1, alternate=1, fuse=3, pair_ty=12, xcd=1, arith=1),
-    "tile4": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1),
-    "fast-tile4": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
-    "fast-tile4-planar": dict(tune=0, layout=0, variant=0, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
-    "fast-col5": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=6, arith=1),
-    "fast-col6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
-    "fast-col6-nt0": dict(tune=0, layout=1, variant=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
-    "col6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7),
-    "fast-deep6": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=1, arith=1),
-    "fast-deep7": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=2, arith=1),
-    "fast-deep8": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=3, arith=1),
-    "deep7": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=2),
-    "deep8": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=3),
+    "site": dict(tune=0, layout=1, nt=1, alternate=0, fuse=1),
+    "vec": dict(tune=0, layout=0, nt=0, alternate=1, fuse=1),
+    "tile2": dict(tune=0, layout=0, nt=1, alternate=0, fuse=2, pair_ty=12, xcd=0),
+    "tile3": dict(tune=0, layout=0, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=0),
+    "tile3-rowil": dict(tune=0, layout=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1),
+    "fast-tile3": dict(tune=0, layout=0, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=0, arith=1),
+    "fast-tile3-rowil-xcd": dict(tune=0, layout=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
+    "fast-tile3-rowil-xcd-8": dict(tune=0, layout=1, nt=1, alternate=0, fuse=3, pair_ty=8, xcd=1, arith=1),
+    "tile3-rowil-xcd": dict(tune=0, layout=1, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1),
+    "ft3-nt0-alt0": dict(tune=0, layout=1, nt=0, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
+    "ft3-nt0-alt1": dict(tune=0, layout=1, nt=0, alternate=1, fuse=3, pair_ty=12, xcd=1, arith=1),
+    "ft3-nt1-alt1": dict(tune=0, layout=1, nt=1, alternate=1, fuse=3, pair_ty=12, xcd=1, arith=1),
+    "ft3-planar-xcd": dict(tune=0, layout=0, nt=1, alternate=0, fuse=3, pair_ty=12, xcd=1, arith=1),
+    "ft3-planar-xcd-alt": dict(tune=0, layout=0, nt=1, alternate=1, fuse=3, pair_ty=12, xcd=1, arith=1),
+    "tile4": dict(tune=0, layout=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1),
+    "fast-tile4": dict(tune=0, layout=1, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
+    "fast-tile4-planar": dict(tune=0, layout=0, nt=1, alternate=0, fuse=4, pair_ty=8, xcd=1, arith=1),
+    "fast-col5": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=6, arith=1),
+    "fast-col6": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
+    "fast-col6-nt0": dict(tune=0, layout=1, nt=0, alternate=0, pair_ty=12, xcd=1, deep=7, arith=1),
+    "col6": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=7),
+    "fast-deep6": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=1, arith=1),
+    "fast-deep7": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=2, arith=1),
+    "fast-deep8": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=3, arith=1),
+    "deep7": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=2),
+    "deep8": dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=3),
     "fast-auto": dict(arith=1),
-    "fast-site": dict(tune=0, layout=1, variant=1, nt=1, alternate=0, fuse=1, arith=1),
-    "fast-vec": dict(tune=0, layout=0, variant=0, nt=0, alternate=1, fuse=1, arith=1),
+    "fast-site": dict(tune=0, layout=1, nt=1, alternate=0, fuse=1, arith=1),
+    "fast-vec": dict(tune=0, layout=0, nt=0, alternate=1, fuse=1, arith=1),
 }
 
 

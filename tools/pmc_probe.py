@@ -2,7 +2,7 @@
 """Replays a bench window of the HIP path with a PINNED plan, for a rocprofv3 counter pass around it:
 
     rocprofv3 --pmc FETCH_SIZE -d DIR -o p --output-format csv -- python3 tools/pmc_probe.py --nx 4096 --ny 1024 \
-        --precision f64 --arith 1 --plan "layout=1 variant=1 nt=0 alternate=1 pair_ty=12 xcd=1 fuse=6 deep=7" --steps 20 --reps 12
+        --precision f64 --arith 1 --plan "layout=1 nt=0 alternate=1 pair_ty=12 xcd=1 fuse=6 deep=7" --steps 20 --reps 12
 
 (hardware counters cannot be read inside a timed run: bench.py starts this program as a CHILD under rocprofv3, one pass per
 counter group, after its timed region — so the bytes in its `roofline` belong to the binary and the plan it has just timed.)

@@ -15,8 +15,8 @@ nx, ny = 4096, 1024
 for n in [int(v) for v in sys.argv[1:]] or (1, 2, 4, 8):
     rows = ny // n
     line = [f"N={n} rows={rows}:"]
-    base = dict(tune=0, layout=1, variant=1, nt=1, fuse=3, pair_ty=12, xcd=1, arith=1, trailing_pair=1)
-    deep = dict(tune=0, layout=1, variant=1, nt=1, pair_ty=12, xcd=1, arith=1, trailing_pair=1, deep=7)      # k_stepc_col, six iterations per launch
+    base = dict(tune=0, layout=1, nt=1, fuse=3, pair_ty=12, xcd=1, arith=1, trailing_pair=1)
+    deep = dict(tune=0, layout=1, nt=1, pair_ty=12, xcd=1, arith=1, trailing_pair=1, deep=7)      # k_stepc_col, six iterations per launch
     lds6 = dict(deep, deep=1)                                  # k_stepd_tile<64,16,6>: one 1024-thread block per CU, one cell per thread
     for name, opts in (("no-exchange", dict(base)),
                        ("no-exchange lds6", dict(lds6)),
