@@ -251,6 +251,10 @@ struct lbm_ctx {
                          // 1 = device copies, 2 = RCCL send/recv to self on a one-rank communicator
     int deep_halo = 1;       // strips: 1 = one exchange of six rows per TWO launches of up to three iterations (the first launch of a pair is
                              // extended); deep plans exchange after every launch. 2 = deep plans too: twelve rows per two launches of up to six
+    int halo_trim = 0;       // strips: 1 = an exchange carries only the sub-rows the receiver's launches read (9 hr - 9 of the 9 hr sub-rows of a
+                             // face, in five runs: the outermost ghost row is read for its three inbound populations only, the next one
+                             // for all but its three outbound ones); 0 = all nine populations of every row, one contiguous message
+    bool trim_pinned = false;
     int trailing_pair = 0;   // allow an lbm_step call to END on a fused launch (host-staged strips)
     bool mid_pair = false;        // the last launch was the extended first launch of a pair (no exchange after it)
     bool last_was_pair = false;   // the last launch fused several iterations: buf[cur^1] is older than steps_done-1
@@ -266,7 +270,7 @@ struct lbm_ctx {
     int overlap = 1;
     bool overlap_pinned = false, deep_pinned = false;   // set through lbm_set_option: the strip tuner leaves them alone
     int skip_exchange = 0;   // DIAGNOSTIC: issue every launch but no halo traffic (times the compute side of a strip run; results invalid)
-    char sched_desc[640] = "";
+    char sched_desc[800] = "";
     int timed_launches = 0, timed_steps = 0;
     long launches_total = 0;
     // communicator

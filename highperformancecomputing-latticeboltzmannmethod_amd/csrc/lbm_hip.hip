@@ -432,7 +432,7 @@ int lbm_runtime_versions(int* rccl, int* hip_runtime, int* hip_driver) {
 
 const char* lbm_strip_schedule(const lbm_ctx* c) {
     if (!c) return "";
-    static thread_local char out[448];
+    static thread_local char out[1024];
     if (c->graph_failed) snprintf(out, sizeof(out), "%s; launch groups issued call by call (graph capture given up: %s)", c->sched_desc, c->graph_note);
     else if (c->graph_replays > 0) snprintf(out, sizeof(out), "%s; %ld hipGraph replays of %d launch groups", c->sched_desc, c->graph_replays, GRAPH_GROUPS);
     else snprintf(out, sizeof(out), "%s", c->sched_desc);
@@ -635,6 +635,7 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "xcd") c->xcd = (int)value ? 1 : 0;
     else if (k == "arith") { if (value != 0 && value != 1) return fail(LBM_ERR_ARG, "arith must be 0 (strict) or 1 (contracted)"); c->arith = (int)value; }
     else if (k == "deep_halo") { if (value < 0 || value > 2) return fail(LBM_ERR_ARG, "deep_halo must be 0, 1 or 2"); c->deep_halo = (int)value; c->deep_pinned = true; }
+    else if (k == "halo_trim") { if (value != 0 && value != 1) return fail(LBM_ERR_ARG, "halo_trim must be 0 or 1"); c->halo_trim = (int)value; c->trim_pinned = true; }
     else if (k == "skip_exchange") c->skip_exchange = (int)value ? 1 : 0;
     else if (k == "group_threads") c->group_threads = (int)value ? 1 : 0;
     else if (k == "wait_timeout_ms") { if (value < 0) return fail(LBM_ERR_ARG, "wait_timeout_ms must be >= 0 (0: LBM_WAIT_TIMEOUT_MS or five minutes)"); c->wait_timeout_ms = value; }
@@ -733,19 +734,28 @@ int lbm_debug_strict_div2(const double* a1, const double* a2, const double* b, i
 
 /* TEST HOOK (no device needed): the decision tune_strip_schedule takes from per-rank pins. ranks x {tune-able, overlap_pinned,
  * overlap, deep_pinned, deep_halo}; returns LBM_OK and the agreed {go, overlap_pinned, overlap, deep_pinned, deep_halo} or LBM_ERR_ARG. */
-int lbm_debug_strip_pins(const int* per_rank5, int nranks, int* agreed5) {
-    if (!per_rank5 || !agreed5 || nranks < 1) return fail(LBM_ERR_ARG, "null argument");
-    double m[5] = {1e30, 1e30, 1e30, 1e30, 1e30};
+int lbm_debug_strip_pins(const int* per_rank7, int nranks, int* agreed7) {
+    if (!per_rank7 || !agreed7 || nranks < 1) return fail(LBM_ERR_ARG, "null argument");
+    double m[7] = {1e30, 1e30, 1e30, 1e30, 1e30, 1e30, 1e30};
     for (int r = 0; r < nranks; ++r) {
-        double v[5];
-        const int* q = per_rank5 + 5 * r;
-        strip_pins_pack(q[0] != 0, q[1] != 0, q[2], q[3] != 0, q[4], v);
-        for (int k = 0; k < 5; ++k) m[k] = std::min(m[k], v[k]);        // what allreduce_doubles(..., MIN) returns on every rank
+        double v[7];
+        const int* q = per_rank7 + 7 * r;
+        strip_pins_pack(q[0] != 0, q[1] != 0, q[2], q[3] != 0, q[4], q[5] != 0, q[6], v);
+        for (int k = 0; k < 7; ++k) m[k] = std::min(m[k], v[k]);        // what allreduce_doubles(..., MIN) returns on every rank
     }
-    agreed5[2] = agreed5[4] = -1;
-    if (!strip_pins_agree(m, &agreed5[0], &agreed5[1], &agreed5[2], &agreed5[3], &agreed5[4]))
+    agreed7[2] = agreed7[4] = agreed7[6] = -1;
+    if (!strip_pins_agree(m, &agreed7[0], &agreed7[1], &agreed7[2], &agreed7[3], &agreed7[4], &agreed7[5], &agreed7[6]))
         return fail(LBM_ERR_ARG, "the ranks pin different strip schedules");
     return LBM_OK;
+}
+
+/* TEST HOOK (no device needed): the runs of the halo message of a face of `hr` rows (csrc/lbm_strips.inc.hpp face_runs): up to five
+ * {first sub-row, sub-rows} pairs relative to the block's first sub-row; south_block: the block lies below the strip it borders. */
+int lbm_debug_face_runs(int hr, int trim, int south_block, int* runs10) {
+    if (!runs10 || hr < 1) return fail(LBM_ERR_ARG, "bad argument");
+    const FaceRuns r = face_runs(hr, trim != 0, south_block != 0);
+    for (int k = 0; k < r.n; ++k) { runs10[2 * k] = r.off[k]; runs10[2 * k + 1] = r.cnt[k]; }
+    return r.n;
 }
 
 /* TEST HOOK (no device needed): dry run of the launch choreography of a strip run and its check (csrc/lbm_choreo.inc.hpp). */

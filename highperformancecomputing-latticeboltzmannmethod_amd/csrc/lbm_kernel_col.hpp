@@ -80,7 +80,14 @@ __device__ __forceinline__ bool unstable_if(const T (&f)[Q], bool valid) {
 // load together and compute together instead of filling each other's gaps, which the dispatcher's staggered hand-out gives
 // for free; the loop also costs registers (every loop-invariant scalar offset wants an SGPR for the whole kernel: 106 SGPRs,
 // > 100 spilled, 164 -> 142 GLUPS even when launched one block per tile). Gone.
-template <typename T, int R, int NW, int D, bool NT, int AR = AR_STRICT>
+// SYNC (round 5): how the waves of a block meet between two levels. 0: one __syncthreads() per level (the library's
+// kernels). 1: NEIGHBOUR FLAGS — a wave publishes the level it has written its six exchange values for in an LDS word and waits for
+// the words of the wave below and the wave above only, so a block's fast waves start level 2 while its slowest wave still waits
+// for its level-1 loads (the phase record of round 4: ~11 us of a block's 21 us are spent behind the first barrier). The exchange
+// buffer stays double-buffered: a wave rewrites buffer L & 1 at level L + 2, after it has seen both neighbours at level L + 1, i.e.
+// after they have finished the reads of level L. Every wave is resident (one block), so the waits are bounded by construction.
+// Measured in tools/colbench (profiles/r05/README.md); the library builds SYNC 0.
+template <typename T, int R, int NW, int D, bool NT, int AR = AR_STRICT, int SYNC = 0>
 __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_col(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int H = R * NW, HW = D - 1, OW = 64 - 2 * HW, OH = H - 2 * HW, LW = 64 + 2;
     static_assert(D >= 2 && OH >= 1 && R >= 2, "(D <= GR on a strip: its ghost rows go GR deep — the host's business)");
@@ -89,8 +96,13 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
     // that are garbage anyway: round 4 dropped the two phantom slots, 63 -> 51 KB at 8 fp64 waves, so that 12 waves fit two
     // blocks per CU); one pad column on each side for the diagonal reads at lane -/+ 1
     __shared__ T xbuf[2][NW][6][LW];
+    [[maybe_unused]] __shared__ int wave_level[SYNC ? NW : 1];
     const int lane = (int)threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if constexpr (SYNC != 0) {       // (before the early return below: every wave of the block passes this barrier or none does)
+        if (lane == 0) wave_level[w] = 1;
+        __syncthreads();
+    }
     const int nbx = (a.nx + OW - 1) / OW, nby = (a.y_cnt + OH - 1) / OH + (a.y_cnt2 + OH - 1) / OH, nb = nbx * nby;
     int b = blockIdx.x;
     { const int per = (int)gridDim.x >> 3; b = (b & 7) * per + (b >> 3); }                   // gridDim.x is a multiple of 8
@@ -173,7 +185,14 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
             const int wb = w > 0 ? w - 1 : 0, wa = w + 1 < NW ? w + 1 : NW - 1;
             xb[w][0][1 + lane] = g[R - 1][2]; xb[w][1][1 + lane] = g[R - 1][5]; xb[w][2][1 + lane] = g[R - 1][6];
             xb[w][3][1 + lane] = g[0][4];     xb[w][4][1 + lane] = g[0][7];     xb[w][5][1 + lane] = g[0][8];
-            __syncthreads();
+            if constexpr (SYNC == 0) __syncthreads();
+            else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the six values are in LDS ...
+                if (lane == 0) *(volatile int*)&wave_level[w] = L;                   // ... before the word that says so
+                while (__builtin_amdgcn_readfirstlane(*(volatile int*)&wave_level[wb]) < L) { if constexpr (SYNC == 1) __builtin_amdgcn_s_sleep(1); }
+                while (__builtin_amdgcn_readfirstlane(*(volatile int*)&wave_level[wa]) < L) { if constexpr (SYNC == 1) __builtin_amdgcn_s_sleep(1); }      // (SYNC 2: busy poll)
+                asm volatile("" ::: "memory");
+            }
             // from the wave below (its top row): f2 at x, f5 at x-1, f6 at x+1; from the wave above (its bottom row): f4, f7 at x+1, f8 at x-1
             T p2 = xb[wb][0][1 + lane], p5 = xb[wb][1][lane], p6 = xb[wb][2][2 + lane];
             bool badl = false;

@@ -71,6 +71,37 @@ inline void rec_xfer(lbm_ctx* c, int kind, hipStream_t s, int buf, long write_of
     c->rec->ops.push_back(o);
 }
 
+// The TRIMMED message (round 5; option "halo_trim", measured like the rest of the schedule): what the receiver's launches really read
+// of the hr rows of a face. Between two exchanges a strip advances at most hr iterations, so of ghost row g (1 = next to the strip)
+// only the populations that can still reach the strip matter: rows 1 .. hr-2 all nine, row hr-1 all but the three that move AWAY from
+// the strip (they would feed level 1 of row hr, which nobody computes), row hr the three that move TOWARDS it — 9 hr - 9 of the 9 hr
+// sub-rows (45 of 54 at hr = 6: 17 % fewer bytes), in five runs of the row-interleaved layout [row][population][column]. Sub-rows that
+// do not travel keep stale but finite values that no valid cell ever reads. Runs are in sub-rows, relative to the first sub-row of the
+// block; `south_block`: the block lies BELOW the strip it borders (a sender's top rows seen from the receiver / a receiver's south
+// ghost rows): its outermost row is the FIRST in memory and "towards the strip" is north (populations 2, 5, 6). Otherwise (a sender's
+// bottom rows / a receiver's north ghost rows) the outermost row is the LAST and "towards the strip" is south (4, 7, 8).
+struct FaceRuns { int n; int off[5], cnt[5]; };
+inline FaceRuns face_runs(int hr, bool trim, bool south_block) {
+    FaceRuns r{};
+    if (!trim || hr < 2) { r.n = 1; r.off[0] = 0; r.cnt[0] = Q * hr; return r; }
+    r.n = 5;
+    if (south_block) {      // row 0 (outermost): {2}, {5,6}; row 1: {0..3}, {5,6}; rows 2 .. hr-1: everything
+        const int o[5] = {2, 5, Q + 0, Q + 5, 2 * Q}, n[5] = {1, 2, 4, 2, Q * (hr - 2)};
+        for (int k = 0; k < 5; ++k) { r.off[k] = o[k]; r.cnt[k] = n[k]; }
+    } else {                // rows 0 .. hr-3: everything, then row hr-2: {0,1}, {3,4}, {7,8}; row hr-1 (outermost): {4}, {7,8}
+        const int a = Q * (hr - 2), b = Q * (hr - 1);
+        const int o[5] = {0, a + 3, a + 7, b + 4, b + 7}, n[5] = {a + 2, 2, 2, 1, 2};
+        for (int k = 0; k < 5; ++k) { r.off[k] = o[k]; r.cnt[k] = n[k]; }
+    }
+    return r;
+}
+inline size_t face_payload_elems(const lbm_ctx* c) {      // elements per face and exchange that really travel
+    const FaceRuns r = face_runs(halo_rows(c), c->halo_trim != 0, true);
+    size_t n = 0;
+    for (int k = 0; k < r.n; ++k) n += (size_t)r.cnt[k];
+    return n * c->pitch0;
+}
+
 // Transports of ONE context: RCCL send/recv between processes (rank r <-> r-1, r+1), or the test-only loopbacks.
 template <typename T>
 int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
@@ -89,33 +120,44 @@ int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
     }
     T* b = static_cast<T*>(c->buf[dst]);
     const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+    const int hr = halo_rows(c);
+    const bool trim = c->halo_trim != 0;
+    const size_t sub = (size_t)c->pitch0;                        // elements of one sub-row
+    // my top rows and my south ghost rows are "south blocks" (below the strip they border), my bottom rows and north ghost rows are not
+    const FaceRuns south_runs = face_runs(hr, trim, true), north_runs = face_runs(hr, trim, false);
     if (c->loopback) {   // test transports: my own edge rows become my ghost rows
         if (c->layout != 1) return fail(LBM_ERR_COMM, "loopback requires the row-interleaved layout");
         if (c->loopback == 2) {   // ... through RCCL itself: a one-rank communicator sending to / receiving from rank 0
             if (!c->comm) return fail(LBM_ERR_COMM, "loopback=2 needs lbm_comm_init(c, 0, 1, id)");
             NCCLCHK(ncclGroupStart());        // self send/recv pairs match in posting order
-            NCCLCHK(ncclSend(b + f.top_rows, f.cnt, dt, 0, c->comm, s));
-            NCCLCHK(ncclRecv(b + f.ghost_s, f.cnt, dt, 0, c->comm, s));
-            NCCLCHK(ncclSend(b + f.bot_rows, f.cnt, dt, 0, c->comm, s));
-            NCCLCHK(ncclRecv(b + f.ghost_n, f.cnt, dt, 0, c->comm, s));
+            for (int k = 0; k < south_runs.n; ++k) {
+                NCCLCHK(ncclSend(b + f.top_rows + south_runs.off[k] * sub, south_runs.cnt[k] * sub, dt, 0, c->comm, s));
+                NCCLCHK(ncclRecv(b + f.ghost_s + south_runs.off[k] * sub, south_runs.cnt[k] * sub, dt, 0, c->comm, s));
+            }
+            for (int k = 0; k < north_runs.n; ++k) {
+                NCCLCHK(ncclSend(b + f.bot_rows + north_runs.off[k] * sub, north_runs.cnt[k] * sub, dt, 0, c->comm, s));
+                NCCLCHK(ncclRecv(b + f.ghost_n + north_runs.off[k] * sub, north_runs.cnt[k] * sub, dt, 0, c->comm, s));
+            }
             NCCLCHK(ncclGroupEnd());
             return LBM_OK;
         }
-        const size_t bytes = f.cnt * sizeof(T);                   // ... or plain device copies on the same stream
-        HIPCHK(hipMemcpyAsync(b + f.ghost_s, b + f.top_rows, bytes, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(b + f.ghost_n, b + f.bot_rows, bytes, hipMemcpyDeviceToDevice, s));
+        for (int k = 0; k < south_runs.n; ++k)                   // ... or plain device copies on the same stream
+            HIPCHK(hipMemcpyAsync(b + f.ghost_s + south_runs.off[k] * sub, b + f.top_rows + south_runs.off[k] * sub, south_runs.cnt[k] * sub * sizeof(T), hipMemcpyDeviceToDevice, s));
+        for (int k = 0; k < north_runs.n; ++k)
+            HIPCHK(hipMemcpyAsync(b + f.ghost_n + north_runs.off[k] * sub, b + f.bot_rows + north_runs.off[k] * sub, north_runs.cnt[k] * sub * sizeof(T), hipMemcpyDeviceToDevice, s));
         return LBM_OK;
     }
     if (c->nranks <= 1) return LBM_OK;
     if (c->layout != 1) return fail(LBM_ERR_COMM, "strips require the row-interleaved layout");
+    // (the k-th send to a peer meets the peer's k-th receive from me: both sides walk the same runs in the same order)
     NCCLCHK(ncclGroupStart());
     if (c->rank + 1 < c->nranks) {
-        NCCLCHK(ncclSend(b + f.top_rows, f.cnt, dt, c->rank + 1, c->comm, s));
-        NCCLCHK(ncclRecv(b + f.ghost_n, f.cnt, dt, c->rank + 1, c->comm, s));
+        for (int k = 0; k < south_runs.n; ++k) NCCLCHK(ncclSend(b + f.top_rows + south_runs.off[k] * sub, south_runs.cnt[k] * sub, dt, c->rank + 1, c->comm, s));
+        for (int k = 0; k < north_runs.n; ++k) NCCLCHK(ncclRecv(b + f.ghost_n + north_runs.off[k] * sub, north_runs.cnt[k] * sub, dt, c->rank + 1, c->comm, s));
     }
     if (c->rank > 0) {
-        NCCLCHK(ncclSend(b + f.bot_rows, f.cnt, dt, c->rank - 1, c->comm, s));
-        NCCLCHK(ncclRecv(b + f.ghost_s, f.cnt, dt, c->rank - 1, c->comm, s));
+        for (int k = 0; k < north_runs.n; ++k) NCCLCHK(ncclSend(b + f.bot_rows + north_runs.off[k] * sub, north_runs.cnt[k] * sub, dt, c->rank - 1, c->comm, s));
+        for (int k = 0; k < south_runs.n; ++k) NCCLCHK(ncclRecv(b + f.ghost_s + south_runs.off[k] * sub, south_runs.cnt[k] * sub, dt, c->rank - 1, c->comm, s));
     }
     NCCLCHK(ncclGroupEnd());
     return LBM_OK;
@@ -137,17 +179,21 @@ int pull_halos(lbm_ctx** cs, int n, int k, int dst) {
     const FaceSpans f = face_spans(c);
     T* b = static_cast<T*>(c->buf[dst]);
     hipStream_t s = exchange_stream(c);
-    const size_t bytes = f.cnt * sizeof(T);
-    auto pull = [&](lbm_ctx* nb, long nb_rows, long my_ghost) -> int {
+    const size_t sub = (size_t)c->pitch0;
+    auto pull = [&](lbm_ctx* nb, long nb_rows, long my_ghost, bool south_block) -> int {
         const T* src = static_cast<const T*>(nb->buf[dst]) + nb_rows;
         QCHK(q_wait(c, s, nb, nb->ev_edge));            // the neighbour's edge rows of this launch are written
         if (c->rec) { rec_xfer(c, ChoreoOp::COPY, s, dst, my_ghost, nb_rows, halo_rows(c), nb); return LBM_OK; }
-        if (nb->device == c->device) HIPCHK(hipMemcpyAsync(b + my_ghost, src, bytes, hipMemcpyDeviceToDevice, s));
-        else HIPCHK(hipMemcpyPeerAsync(b + my_ghost, c->device, src, nb->device, bytes, s));
+        const FaceRuns r = face_runs(halo_rows(c), c->halo_trim != 0, south_block);
+        for (int q = 0; q < r.n; ++q) {
+            const size_t o = r.off[q] * sub, bytes = r.cnt[q] * sub * sizeof(T);
+            if (nb->device == c->device) HIPCHK(hipMemcpyAsync(b + my_ghost + o, src + o, bytes, hipMemcpyDeviceToDevice, s));
+            else HIPCHK(hipMemcpyPeerAsync(b + my_ghost + o, c->device, src + o, nb->device, bytes, s));
+        }
         return LBM_OK;
     };
-    if (k > 0) { int rc = pull(cs[k - 1], face_spans(cs[k - 1]).top_rows, f.ghost_s); if (rc) return rc; }
-    if (k + 1 < n) { int rc = pull(cs[k + 1], face_spans(cs[k + 1]).bot_rows, f.ghost_n); if (rc) return rc; }
+    if (k > 0) { int rc = pull(cs[k - 1], face_spans(cs[k - 1]).top_rows, f.ghost_s, true); if (rc) return rc; }
+    if (k + 1 < n) { int rc = pull(cs[k + 1], face_spans(cs[k + 1]).bot_rows, f.ghost_n, false); if (rc) return rc; }
     return LBM_OK;
 }
 
@@ -173,13 +219,15 @@ int exchange_group(lbm_ctx** cs, int n, int dst) {
             const FaceSpans f = face_spans(c);
             T* b = static_cast<T*>(c->buf[dst]);
             hipStream_t s = exchange_stream(c);
+            const size_t sub = (size_t)c->pitch0;
+            const FaceRuns sr = face_runs(halo_rows(c), c->halo_trim != 0, true), nr = face_runs(halo_rows(c), c->halo_trim != 0, false);
             if (k + 1 < n) {
-                NCCLCHK(ncclSend(b + f.top_rows, f.cnt, dt, k + 1, c->comm, s));
-                NCCLCHK(ncclRecv(b + f.ghost_n, f.cnt, dt, k + 1, c->comm, s));
+                for (int q = 0; q < sr.n; ++q) NCCLCHK(ncclSend(b + f.top_rows + sr.off[q] * sub, sr.cnt[q] * sub, dt, k + 1, c->comm, s));
+                for (int q = 0; q < nr.n; ++q) NCCLCHK(ncclRecv(b + f.ghost_n + nr.off[q] * sub, nr.cnt[q] * sub, dt, k + 1, c->comm, s));
             }
             if (k > 0) {
-                NCCLCHK(ncclSend(b + f.bot_rows, f.cnt, dt, k - 1, c->comm, s));
-                NCCLCHK(ncclRecv(b + f.ghost_s, f.cnt, dt, k - 1, c->comm, s));
+                for (int q = 0; q < nr.n; ++q) NCCLCHK(ncclSend(b + f.bot_rows + nr.off[q] * sub, nr.cnt[q] * sub, dt, k - 1, c->comm, s));
+                for (int q = 0; q < sr.n; ++q) NCCLCHK(ncclRecv(b + f.ghost_s + sr.off[q] * sub, sr.cnt[q] * sub, dt, k - 1, c->comm, s));
             }
         }
         NCCLCHK(ncclGroupEnd());

@@ -187,7 +187,12 @@ int  lbm_load_state(lbm_ctx* c, const char* path);
  *                 plan of up to three iterations per launch (a deep plan still exchanges after every launch) | 2 a deep plan too:
  *                 2 x LBM_HALO_ROWS rows after every second launch of up to six iterations (both measured at lbm_initialise
  *                 when a communicator is attached, unless set here),
+ *                 "halo_trim" 0 an exchange carries all nine populations of every row of a face in ONE contiguous message | 1 only the
+ *                 sub-rows the receiver's launches read (the outermost row's three inbound populations, the next row's six, every
+ *                 other row's nine: 9 hr - 9 of 9 hr sub-rows, five messages per face); measured at lbm_initialise like the rest,
  *                 "skip_exchange" 1 (diagnostic: no halo traffic, results invalid),
+ *                 "wait_timeout_ms" bound of every host-side wait (rendezvous of a group's threads, lbm_sync, the drains of
+ *                 lbm_destroy; 0 = LBM_WAIT_TIMEOUT_MS or five minutes): LBM_ERR_TIMEOUT names who was waited for,
  *                 "graph" 0|1|2 replay the launch groups of a deep strip plan from a captured hipGraph: 1 (default) where the
  *                 transport is local to the process, 2 also between the ranks of a communicator (RCCL under capture:
  *                 exercised with a one-rank communicator only so far)
@@ -216,10 +221,15 @@ const char* lbm_plan_options(const lbm_ctx* c);
  * a2/b, n host doubles each. Bit-identical for denominators in [2^-20, 2^20] and numerators 0 or of magnitude in [2^-400, 2^400]. */
 int lbm_debug_strict_div2(const double* a1, const double* a2, const double* b, int n, double* q1, double* q2, double* r1, double* r2);
 /* Test hook, callable without a device: what the ranks of a strip run agree on before the collective schedule trials of
- * lbm_initialise (csrc/lbm_hip.hip tune_strip_schedule). per_rank5 = nranks x {may tune, overlap pinned, overlap, deep_halo pinned,
- * deep_halo}; agreed5 = {tune, overlap pinned, overlap, deep_halo pinned, deep_halo}. LBM_ERR_ARG when the ranks pin different
+ * lbm_initialise (csrc/lbm_hip.hip tune_strip_schedule). per_rank7 = nranks x {may tune, overlap pinned, overlap, deep_halo pinned,
+ * deep_halo, halo_trim pinned, halo_trim}; agreed7 = the same seven as agreed (-1 where nothing is pinned). LBM_ERR_ARG when the ranks pin different
  * schedules (they would otherwise run different numbers of collective trials). Replaces nothing in the reference. */
-int lbm_debug_strip_pins(const int* per_rank5, int nranks, int* agreed5);
+int lbm_debug_strip_pins(const int* per_rank7, int nranks, int* agreed7);
+/* Test hook, callable without a device: the runs of the halo message of one face of `hr` rows (option "halo_trim"; csrc/lbm_strips.inc.hpp
+ * face_runs) as up to five {first sub-row, sub-rows} pairs relative to the first sub-row of the block (row-interleaved layout: nine
+ * sub-rows per lattice row); south_block != 0: the block lies below the strip it borders (a sender's top rows / a receiver's south ghost
+ * rows). Returns the number of runs. Replaces the nine-values-per-edge-cell buffers of pack_data_for_sending, LBMGrid.h:395-440. */
+int lbm_debug_face_runs(int hr, int trim, int south_block, int* runs10);
 /* Test hook, callable without a device: the candidate plans lbm_initialise would time on a whole-domain context of this grid
  * (csrc/lbm_plan.hpp), one per line: "name|lbm_set_option pairs|dominant kernel|iterations per launch". */
 int lbm_debug_plan_candidates(int nx, int ny, int precision, int arith, int num_cus, char* out, int cap);

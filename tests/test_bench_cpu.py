@@ -115,3 +115,32 @@ def test_roofline_object_from_a_committed_pass():
     assert r["stale"] is True and len(r["traffic_build_id"]) == 16 and r["approximate"] is False and "live passes" in r["traffic_source"]
     r5 = b.roofline_of(Lbm, Ctx(), 4096, 1024, "f64", 0.140, 4, 20, 20, live=False)      # a 20-step call: the table's bytes as they are
     assert r5["traffic"] == r["traffic"] and r5["traffic_iterations_per_launch"] == 6.0
+
+
+def test_committed_bench_lines_of_the_current_round_belong_to_their_build():
+    """round 4 committed six per-grid bench lines flagged `stale: true` (written before the traffic table of their
+    build existed). From round 5 on: every profiles/rNN/*/bench_line.json and profiles/rNN/bench_*.json of rounds >= 5 must carry
+    counter bytes of its OWN build — traffic_build_id == config.build_id, neither `stale` nor `approximate`, in the headline's roofline
+    and in the single-precision variant's where there is one."""
+    import glob
+    import re
+    checked = 0
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]"))):
+        if int(os.path.basename(d)[1:]) < 5:
+            continue
+        for f in sorted(glob.glob(os.path.join(d, "*", "bench_line.json")) + glob.glob(os.path.join(d, "bench_*.json"))):
+            text = open(f).read().strip()
+            if not text:
+                continue
+            line = json.loads(text.splitlines()[-1])
+            build = line["config"]["build_id"]
+            roofs = [("roofline", line["roofline"])]
+            if isinstance(line.get("single_precision_variant"), dict) and "error" not in line["single_precision_variant"]:
+                roofs.append(("single_precision_variant", line["single_precision_variant"]))
+            for name, r in roofs:
+                assert r.get("traffic") is not None, (f, name, "no counter bytes")
+                assert r.get("traffic_build_id") == build, (f, name, r.get("traffic_build_id"), build)
+                assert r.get("stale") is False and r.get("approximate") is False, (f, name, r.get("stale"), r.get("approximate"))
+            checked += 1
+    assert checked >= 0      # (no round-5 record yet while the round is being built: nothing to check is not a failure)
+

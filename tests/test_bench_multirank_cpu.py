@@ -13,7 +13,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(scenario, world=2, extra=()):
+def run_bench(scenario, world=2, extra=(), grid=("64", "48")):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -21,9 +21,9 @@ def run_bench(scenario, world=2, extra=()):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_bench_worker.py"), scenario, "--gpus", str(world),
-                                       "--steps", "20", "--warmup", "5", "--nx", "64", "--ny", "48", *extra],
+                                       "--steps", "20", "--warmup", "5", "--nx", grid[0], "--ny", grid[1], *extra],
                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=300) for p in procs]
+    outs = [p.communicate(timeout=900) for p in procs]
     return [p.returncode for p in procs], outs
 
 
@@ -50,3 +50,22 @@ def test_a_strip_mismatch_voids_the_line_on_every_rank():
     line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][0])
     assert line["value"] is None and line["value_unverified"] > 0 and line["strips"]["parity"].startswith("MISMATCH: rank 1")
     assert "INVALID" in outs[0][1]
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("nx,ny,precision,label", [(8192, 2048, "f64", "configs[3]"), (16384, 4096, "f32", "configs[4]")])
+def test_the_two_eight_gpu_configs_of_baseline_json_run_end_to_end(nx, ny, precision, label):
+    """VERDICT r04 #7b: `bench.py --gpus N --nx 8192 --ny 2048` and `--nx 16384 --ny 4096 --precision f32` are the two 8-GPU
+    configurations BASELINE.json names; the first run of either is the driver's. Here on two gloo ranks with the compute-free
+    stand-in: the workload label names the config, the strips split the named grid (strong scaling), the parity window compares
+    every row of the full-size grid (the gather and the checksum path at 2 x 2.4 GB), dtype and metric follow the precision, exit 0."""
+    rcs, outs = run_bench("ok", extra=("--precision", precision), grid=(str(nx), str(ny)))
+    assert rcs == [0, 0], [o[1][-2000:] for o in outs]
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][0])
+    assert label in line["config"]["workload"] and f"{nx}x{ny} {precision}" in line["config"]["workload"]
+    assert line["dtype"] == precision and line["metric"] == f"MLUPS ({'fp64' if precision == 'f64' else 'fp32'})"
+    assert line["config"]["rows_per_gpu"] == ny // 2 and line["config"]["decomposition"] == "2 row strip(s)" and line["scaling"] == "strong"
+    st = line["strips"]
+    assert st["parity"] == "bit-equal" and [r["rows"] for r in st["per_rank"]] == [ny // 2, ny // 2]
+    assert line["value"] > 0 and line["roofline"]["algorithmic_bytes_per_launch"] > 0
+

@@ -90,21 +90,58 @@ def test_strip_schedule_pins_are_agreed_over_the_ranks(pkg):
     lib.lbm_debug_strip_pins.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
 
     def agree(ranks):
-        flat = (ctypes.c_int * (5 * len(ranks)))(*[v for r in ranks for v in r])
-        out = (ctypes.c_int * 5)()
+        ranks = [tuple(r) + (0, 0) if len(r) == 5 else tuple(r) for r in ranks]        # (halo_trim unpinned unless given)
+        flat = (ctypes.c_int * (7 * len(ranks)))(*[v for r in ranks for v in r])
+        out = (ctypes.c_int * 7)()
         rc = lib.lbm_debug_strip_pins(flat, len(ranks), out)
-        return rc, list(out)
+        return rc, list(out)[:5], list(out)[5:]
 
     # nobody pins anything: tune, nothing pinned
-    assert agree([(1, 0, 1, 0, 1)] * 4) == (0, [1, 0, -1, 0, -1])
+    assert agree([(1, 0, 1, 0, 1)] * 4)[:2] == (0, [1, 0, -1, 0, -1])
     # everybody pins overlap=2: agreed, the deep-halo half is still measured
-    assert agree([(1, 1, 2, 0, 1)] * 3) == (0, [1, 1, 2, 0, -1])
+    assert agree([(1, 1, 2, 0, 1)] * 3)[:2] == (0, [1, 1, 2, 0, -1])
     # one strip too short to tune: nobody tunes
-    rc, out = agree([(1, 0, 1, 0, 1), (0, 0, 1, 0, 1)])
+    rc, out, _ = agree([(1, 0, 1, 0, 1), (0, 0, 1, 0, 1)])
     assert rc == 0 and out[0] == 0
     # one rank pins overlap, the other does not / pins another value: error on every rank
     assert agree([(1, 1, 1, 0, 1), (1, 0, 1, 0, 1)])[0] < 0
     assert agree([(1, 1, 1, 0, 1), (1, 1, 0, 0, 1)])[0] < 0
     assert agree([(1, 0, 1, 1, 0), (1, 0, 1, 1, 1)])[0] < 0
+    # the message trimming (round 5) is a third pin of the same kind
+    assert agree([(1, 0, 1, 0, 1, 1, 1)] * 2) == (0, [1, 0, -1, 0, -1], [1, 1])
+    assert agree([(1, 0, 1, 0, 1, 1, 1), (1, 0, 1, 0, 1, 0, 0)])[0] < 0 and agree([(1, 0, 1, 0, 1, 1, 1), (1, 0, 1, 0, 1, 1, 0)])[0] < 0
     # both halves pinned alike everywhere
-    assert agree([(1, 1, 0, 1, 1)] * 8) == (0, [1, 1, 0, 1, 1])
+    assert agree([(1, 1, 0, 1, 1)] * 8)[:2] == (0, [1, 1, 0, 1, 1])
+
+
+def test_the_trimmed_halo_message_is_exactly_what_the_receiver_reads(pkg):
+    """Option "halo_trim" (round 5, VERDICT r04 #7a): of the hr rows of a face an exchange need carry only what can still reach the
+    strip in the hr iterations until the next exchange. Derived here independently of the library from the dependency cone — ghost
+    row g (1 = next to the strip) is read for level 1 of rows g-1, g, g+1, and level 1 is computed on rows 1 .. hr-1 only: population
+    i of row g travels iff some row in 1 .. hr-1 pulls it, i.e. iff g - cy_toward(i) is such a row — and compared with the runs the
+    transports walk (lbm_debug_face_runs), for every frame depth the schedules use (six, seven, eight and twelve rows)."""
+    lib = ctypes.CDLL(pkg.lib_path())
+    lib.lbm_debug_face_runs.argtypes = [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int)]
+    cy = [0, 0, 1, 0, -1, 1, 1, -1, -1]
+    for hr in (6, 7, 8, 12):
+        for south_block in (1, 0):
+            out = (ctypes.c_int * 10)()
+            n = lib.lbm_debug_face_runs(hr, 1, south_block, out)
+            assert n == 5
+            got = set()
+            for k in range(n):
+                assert out[2 * k + 1] > 0
+                got |= set(range(out[2 * k], out[2 * k] + out[2 * k + 1]))
+            assert len(got) == sum(out[2 * k + 1] for k in range(n)) == 9 * hr - 9        # disjoint runs, 45 of 54 at six rows
+            want = set()
+            for g in range(1, hr + 1):
+                # memory row of ghost row g inside the block: a block below its strip stores the outermost row first
+                mem = hr - g if south_block else g - 1
+                for i in range(9):
+                    toward = cy[i] if south_block else -cy[i]        # +1: the population moves towards the strip, -1: away from it
+                    puller = g - toward                               # the ghost row (0 = the strip's own edge row) whose level 1 pulls it
+                    if 0 <= puller <= hr - 1:
+                        want.add(9 * mem + i)
+            assert got == want, (hr, south_block, sorted(want - got), sorted(got - want))
+            assert lib.lbm_debug_face_runs(hr, 0, south_block, out) == 1 and (out[0], out[1]) == (0, 9 * hr)
+

@@ -419,3 +419,47 @@ def test_fp32_contracted_plans_agree_bit_for_bit_at_1024x256(lbm):
     for name, (fn, kernel) in out.items():
         assert np.array_equal(fn, out["site"][0]), (name, kernel)
 
+
+def test_the_trimmed_halo_message_is_result_invariant(lbm):
+    """Option "halo_trim" 1 (round 5, VERDICT r04 #7a): an exchange carries 9 hr - 9 of the 9 hr sub-rows of a face, in five messages
+    — what tests/test_cabi_cpu.py derives from the dependency cone. The sub-rows that never travel go stale; no valid cell may read
+    them: groups of three uneven strips (peer copies) on every frame depth the schedules use — six rows (three-iteration pairs, the
+    six-iteration LDS and register shapes), seven ("deep" 9), eight ("deep" 3), twelve ("deep_halo" 2) — across force outputs == the
+    whole domain bit for bit, and one strip over the one-rank RCCL transport, eager and replayed from a graph, == untrimmed.
+    (Replaces pack_data_for_sending / unpack_received_data, /root/reference/include/LBMGrid.h:395-491, which move all nine values.)"""
+    nx, ny, steps, of = 320, 300, 233, 50
+    kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
+    bounds = [(0, 130), (130, 40), (170, 130)]
+    for arith in (0, 1):
+        with lbm.Context(nx, ny, options=dict(tune=0, layout=1, nt=1, alternate=0, fuse=1, arith=arith), **kw) as whole:
+            whole.initialise()
+            whole.step(steps, of)
+            w_fn, w_log = whole.populations("f_next"), whole.drain_force_log()
+        for plan in (dict(fuse=3, pair_ty=12, deep_halo=1), dict(fuse=3, pair_ty=8, deep_halo=0), dict(deep=1, deep_halo=1), dict(deep=7, deep_halo=1), dict(deep=7, deep_halo=2),
+                     dict(deep=6, deep_halo=2), dict(deep=9, deep_halo=1), dict(deep=3, deep_halo=1), dict(deep=2, deep_halo=1)):
+            for overlap in (0, 1, 2):
+                opts = dict(tune=0, layout=1, nt=1, alternate=0, xcd=1, arith=arith, overlap=overlap, halo_trim=1, **plan)
+                with lbm.Group(nx, ny, bounds, options=opts, **kw) as g:
+                    g.initialise()
+                    assert "halo_trim=1" in g.ctxs[1].strip_schedule()
+                    g.step(steps, of)
+                    assert g.first_unstable_step() == -1
+                    assert np.array_equal(g.populations("f_next"), w_fn), opts
+                    assert [r[0] for r in g.drain_force_log()] == [r[0] for r in w_log]
+    out = []
+    for trim, loopback, overlap, graph, deep in ((0, 1, 0, 0, 7), (1, 1, 1, 0, 7), (1, 2, 1, 0, 7), (1, 2, 1, 1, 7), (1, 2, 0, 1, 7)):
+        with lbm.Context(512, 200, options=dict(tune=0, layout=1, nt=1, alternate=0, xcd=1, deep=deep, arith=1, loopback=loopback, overlap=overlap, graph=graph,
+                                                halo_trim=trim, deep_halo=1), **kw) as ctx:
+            if loopback == 2:
+                ctx.comm_init(0, 1, ctx.comm_unique_id())
+            ctx.initialise()
+            ctx.step(333, 160)
+            ctx.sync()
+            assert ctx.first_unstable_step() == -1
+            sched = ctx.strip_schedule()
+            assert f"halo_trim={trim}" in sched and (f"{(54 - 9 * trim) * 544 * 8} B per face and exchange" in sched), sched
+            assert (ctx.graph_replays() > 0) == (graph == 1), sched
+            out.append((ctx.populations("f_next")[1:-1], ctx.drain_force_log()))
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0]) and out[0][1] == other[1]
+

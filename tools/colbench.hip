@@ -5,8 +5,7 @@
 //
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -o tools/colbench tools/colbench.hip
 //        (+ -DLBM_COL_PROF -o tools/colbench_prof: in-kernel phase record, `--prof DIR --filter NAME`)
-#include "experimental/lbm_kernel_slide.hpp"
-#include "experimental/lbm_slide_plan.hpp"
+#include "../highperformancecomputing-latticeboltzmannmethod_amd/csrc/lbm_kernel_col.hpp"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -118,75 +117,19 @@ Variant<T> col_variant(bool nt, bool alt = false, int persist = 0) {
         else hipLaunchKernelGGL((k_stepc_col<T, R, NW, D, false, AR>), grid, dim3(NW * 64), 0, L.s, a, L.extra());
     }};
 }
-// PIPELINED launches: the lattice in P parts of whole tile rows, one kernel and one stream per part; part p of launch n+1 waits for
-// parts p-1, p, p+1 of launch n only (its inputs, and the readers of the rows it overwrites), so it starts while the last part of
-// launch n is still draining: the ramp of one launch fills the drain of the other.
-template <typename T, int R, int NW, int D, int AR>
-Variant<T> pipe_variant(int P, bool alt = false) {
+static int g_cus = 256;
+// round 5: the waves of a block meet through neighbour flags instead of one barrier per level (k_stepc_col<.., SYNC = 1>)
+template <typename T, int R, int NW, int D, int AR, int SYNC = 1>
+Variant<T> colsync_variant(bool alt = false) {
     char nm[96];
-    snprintf(nm, sizeof(nm), "pipe%d R=%d NW=%d D=%d %s", P, R, NW, D, alt ? "alt" : "");
+    snprintf(nm, sizeof(nm), "colsync%d R=%d NW=%d D=%d %s", SYNC, R, NW, D, alt ? "alt" : "");
     return {nm, D, [=](Lattice<T>& L) {
         constexpr int OW = 64 - 2 * (D - 1), OH = R * NW - 2 * (D - 1);
-        L.pipe_init();
-        const int trows = (L.ny + OH - 1) / OH, nbx = (L.nx + OW - 1) / OW;
-        const int par = L.pstep & 1, prev = par ^ 1;
-        for (int k = 0; k < P; ++k) {
-            const int p = (alt && (L.pstep & 1)) ? P - 1 - k : k;
-            const int tr0 = trows * p / P, tr1 = trows * (p + 1) / P;
-            const int y0 = tr0 * OH, y1 = std::min(L.ny, tr1 * OH);
-            if (y1 <= y0) continue;
-            hipStream_t st = L.ps[p];
-            if (L.pstep > 0) {
-                if (p > 0) CK(hipStreamWaitEvent(st, L.pe[prev][p - 1], 0));
-                if (p + 1 < P) CK(hipStreamWaitEvent(st, L.pe[prev][p + 1], 0));
-            }
-            KArgs<T> a = L.args(L.t);
-            a.y_lo = y0; a.y_cnt = y1 - y0;
-            a.reverse = alt ? (L.pstep & 1) : 0;
-            const int nb = nbx * (tr1 - tr0);
-            hipLaunchKernelGGL((k_stepc_col<T, R, NW, D, false, AR>), dim3((nb + 7) / 8 * 8), dim3(NW * 64), 0, st, a, L.extra());
-            CK(hipEventRecord(L.pe[par][p], st));
-            CK(hipStreamWaitEvent(L.s, L.pe[par][p], 0));
-        }
-        ++L.pstep;
-    }};
-}
-// the sliding form (lbm_kernel_slide.hpp): the host deals the segments (lbm_slide_plan.hpp); slots = resident blocks to plan for
-static int g_cus = 256;
-#include <map>
-#include <tuple>
-struct PlanOnDevice { SlideSeg* d = nullptr; int n = 0; int* ticket = nullptr; };
-static int g_stagger = 0;
-template <int D> inline PlanOnDevice slide_table(int nx, int ny, int slots, int H) {
-    static std::map<std::tuple<int, int, int, int>, PlanOnDevice> cache;
-    auto key = std::make_tuple(nx, ny, slots, H);
-    auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
-    SlideGeom g{nx, 0, ny, 0, ny, (int)(0.2 * nx), (int)(0.5 * ny), (int)(0.05 * ny), D, H, slots > 0 ? slots : 2 * g_cus};
-    std::vector<SlideSegHost> plan = slide_plan(g);
-    PlanOnDevice pd; pd.n = (int)plan.size();
-    CK(hipMalloc(&pd.d, sizeof(SlideSeg) * std::max<size_t>(1, plan.size())));
-    CK(hipMemcpy(pd.d, plan.data(), sizeof(SlideSeg) * plan.size(), hipMemcpyHostToDevice));
-    CK(hipMalloc(&pd.ticket, 2048 * sizeof(int))); CK(hipMemset(pd.ticket, 0, 2048 * sizeof(int)));
-    int ng = 0, rows_l = 0, rows_g = 0, maxl = 0, maxg = 0;
-    for (auto& s : plan) { if (s.general) { ++ng; rows_g += s.yb - s.ya; maxg = std::max(maxg, s.yb - s.ya); } else { rows_l += s.yb - s.ya; maxl = std::max(maxl, s.yb - s.ya); } }
-    printf("PLAN %dx%d D=%d slots=%d: %d blocks (%d general), lean rows %d (longest piece %d), general rows %d (longest %d)\n", nx, ny, D, g.slots, pd.n, ng, rows_l, maxl, rows_g, maxg);
-    cache[key] = pd;
-    return pd;
-}
-template <typename T, int R, int NW, int D, int AR>
-Variant<T> slide_variant(bool nt, int slots = 0, int stagger = -1) {
-    char nm[96];
-    snprintf(nm, sizeof(nm), "slide R=%d NW=%d D=%d %s s%d g%d", R, NW, D, nt ? "nt" : "  ", slots, stagger);
-    return {nm, D, [=](Lattice<T>& L) {
-        static_assert(sizeof(SlideSeg) == sizeof(SlideSegHost), "one layout");
-        const PlanOnDevice pd = slide_table<D>(L.nx, L.ny, slots, R * NW);
-        SlideArgs sa; sa.segs = pd.d; sa.nblocks = pd.n; sa.cu_ticket = pd.ticket; sa.stagger = stagger >= 0 ? stagger : g_stagger;
-        dim3 grid((sa.nblocks + 7) / 8 * 8);
+        const int nb = ((L.nx + OW - 1) / OW) * ((L.ny + OH - 1) / OH);
         KArgs<T> a = L.args(L.t);
-        if (nt) hipLaunchKernelGGL((k_steps_col<T, R, NW, D, true, AR>), grid, dim3(NW * 64), 0, L.s, a, L.extra(), sa);
-        else hipLaunchKernelGGL((k_steps_col<T, R, NW, D, false, AR>), grid, dim3(NW * 64), 0, L.s, a, L.extra(), sa);
-    }};
+        a.reverse = alt ? (L.cur & 1) : 0;
+        hipLaunchKernelGGL((k_stepc_col<T, R, NW, D, false, AR, SYNC>), dim3((nb + 7) / 8 * 8), dim3(NW * 64), 0, L.s, a, L.extra());
+    }, NW};
 }
 template <typename T, int TX, int TY, int D, int AR>
 Variant<T> tile_variant() {
@@ -209,6 +152,10 @@ std::vector<Variant<T>> variants() {
     v.push_back(col_variant<T, 4, 8, 6, AR>(true));
     v.push_back(col_variant<T, 4, 8, 6, AR>(false));
     v.push_back(col_variant<T, 4, 8, 6, AR>(false, true));
+    v.push_back(colsync_variant<T, 4, 8, 6, AR>(false));
+    v.push_back(colsync_variant<T, 4, 8, 6, AR>(true));
+    v.push_back(colsync_variant<T, 4, 8, 7, AR>(true));
+    v.push_back(colsync_variant<T, 4, 8, 6, AR, 2>(true));
     v.push_back(col_variant<T, 4, 8, 7, AR>(false));
     v.push_back(col_variant<T, 4, 8, 7, AR>(false, true));
     v.push_back(col_variant<T, 3, 8, 5, AR>(true));
@@ -240,17 +187,6 @@ std::vector<Variant<T>> variants() {
         v.push_back(col_variant<T, 3, 16, 7, AR>(false, true));
         v.push_back(col_variant<T, 2, 16, 6, AR>(false, true));
     }
-    v.push_back(pipe_variant<T, 4, 8, 6, AR>(2));
-    v.push_back(pipe_variant<T, 4, 8, 6, AR>(3));
-    v.push_back(pipe_variant<T, 4, 8, 6, AR>(4));
-    v.push_back(pipe_variant<T, 4, 8, 6, AR>(3, true));
-    v.push_back(slide_variant<T, 4, 8, 6, AR>(false));
-    v.push_back(slide_variant<T, 4, 8, 6, AR>(true));
-    v.push_back(slide_variant<T, 4, 8, 5, AR>(false));
-    v.push_back(slide_variant<T, 4, 8, 6, AR>(false, 0, 1));
-    v.push_back(slide_variant<T, 4, 8, 6, AR>(false, 0, 2));
-    v.push_back(slide_variant<T, 4, 8, 6, AR>(false, 0, 3));
-    v.push_back(slide_variant<T, 4, 8, 6, AR>(false, 0, 5));
     return v;
 }
 
@@ -390,7 +326,6 @@ int main(int argc, char** argv) {
         else if (k == "--prof") profdir = argv[++i];
         else if (k == "--ntl") g_ntl = atoi(argv[++i]);
         else if (k == "--pad") g_pad = atoi(argv[++i]);
-        else if (k == "--stagger") g_stagger = atoi(argv[++i]);
         else if (k == "--map") { g_map = true; mnx = atoi(argv[++i]); mny = atoi(argv[++i]); mlaunch = atoi(argv[++i]); }
     }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, 0) == hipSuccess && pr.multiProcessorCount > 0) g_cus = pr.multiProcessorCount; }

@@ -11,6 +11,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _progress import Progress      # noqa: E402
+PROGRESS = Progress("fuzz_loopback", sys.argv[1] if len(sys.argv) > 1 else "1")      # (sets LBM_TRACE before the library loads)
 lbm = importlib.import_module("highperformancecomputing-latticeboltzmannmethod_amd")
 
 
@@ -41,7 +44,9 @@ def main():
         base = dict(tune=0, layout=1, nt=1, alternate=0, pair_ty=12, xcd=1, deep=1, arith=arith, loopback=1, overlap=0, deep_halo=1, graph=0)
         deep = int(rng.choice([1, 2, 3, 6, 7, 9] + ([8] if precision == "f32" else [])))
         opts = dict(base, deep=deep, nt=int(rng.integers(0, 2)) if deep != 8 else 0, ntl=int(rng.integers(0, 2)), loopback=int(rng.integers(1, 3)),
-                    overlap=int(rng.integers(0, 3)), deep_halo=int(rng.integers(0, 3)), graph=int(rng.integers(0, 2)), trailing_pair=int(rng.integers(0, 2)))
+                    overlap=int(rng.integers(0, 3)), deep_halo=int(rng.integers(0, 3)), graph=int(rng.integers(0, 2)), trailing_pair=int(rng.integers(0, 2)),
+                    halo_trim=int(rng.integers(0, 2)))
+        PROGRESS.start(f"case {k}: {nx}x{rows} {precision} calls={calls} opts={opts}")
         try:
             ref = run(nx, rows, kw, base, calls)
             got = run(nx, rows, kw, opts, calls)
@@ -49,6 +54,7 @@ def main():
         except Exception as e:      # noqa: BLE001
             ok = False
             got = (None, None, None, str(e))
+        PROGRESS.done("ok" if ok else "MISMATCH")
         if not ok:
             bad += 1
             print(f"MISMATCH case {k}: {nx}x{rows} {kw} calls={calls} opts={opts} -> {got[3] if got[0] is None else 'differs'}", flush=True)

@@ -7,16 +7,22 @@ import traceback
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _progress import Progress      # noqa: E402
+PROGRESS = Progress("fuzz_seeds", "_".join(sys.argv[1:]) or "1")      # (sets LBM_TRACE before the library loads)
 import tests.test_gpu_random as t   # noqa: E402
 
 bad = total = 0
 for seed in [int(v) for v in sys.argv[1:]] or [1]:
     for case in t.cases(seed=seed):
         total += 1
+        PROGRESS.start(f"seed {seed} case {case}")
         try:
             t.test_random_case_matches_oracle(case)
+            PROGRESS.done()
         except Exception as e:      # noqa: BLE001
             msg = str(e)
+            PROGRESS.done(f"FAILED {msg[:200]}")
             if "at least 12 rows" in msg or "needs at least" in msg:
                 continue            # (a draw the generator of another seed does not clamp)
             bad += 1
