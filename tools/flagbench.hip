@@ -7,10 +7,11 @@
 //   flags    every block publishes "round r done" (release) and waits for its eight neighbours' words (acquire), `rounds` times:
 //            mode 0 relaxed words only; mode 1 with the agent-scope release / acquire fences a real exchange needs (L2 write-back and
 //            invalidate on gfx950: the L2s of the eight XCDs are not coherent with each other); mode 2 like 1 plus `bytes` of stores
-//            per block and round in front of the release (the tile a block would hand over)
+//            per block and round in front of the release (the tile a block would hand over); mode 3 like 1 with ONE wave per block
+//            executing the acquire (the cheapest correct form)
 //   kernels  the same number of empty launches of the same grid back to back on one stream
 // Every spin is BOUNDED (s_memrealtime, 100 MHz): a block that waits longer than `limit_us` writes its id to an error word, publishes a
-// POISON value so that its neighbours leave too, and exits; `--withhold B R` makes block B skip its word in round R to show it.
+// POISON value so that its neighbours leave too, and exits; `--withhold B R` makes block B publish nothing from round R on to show it.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -o tools/flagbench tools/flagbench.hip
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -51,7 +52,7 @@ __global__ void __launch_bounds__(1024) k_flag_rounds(const FlagArgs p) {
             for (int k = threadIdx.x; k < n; k += blockDim.x) q[k] = (double)(r + k);
         }
         __syncthreads();                                              // every thread's stores are issued (and, with the barrier's fence, performed)
-        if (threadIdx.x == 0 && !(b == p.withhold_block && r == p.withhold_round)) {
+        if (threadIdx.x == 0 && !(b == p.withhold_block && r >= p.withhold_round)) {      // (--withhold B R: block B publishes nothing from round R on)
             if (p.mode >= 1) __atomic_store_n(&p.flags[b], p.epoch0 + r + 1, __ATOMIC_RELEASE);        // agent-scope release: write-back of this XCD's L2
             else __hip_atomic_store(&p.flags[b], p.epoch0 + r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -75,7 +76,8 @@ __global__ void __launch_bounds__(1024) k_flag_rounds(const FlagArgs p) {
             if (threadIdx.x == 0) __hip_atomic_store(&p.flags[b], POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        if (p.mode >= 1) __atomic_thread_fence(__ATOMIC_ACQUIRE);     // agent-scope acquire: what the neighbours wrote is re-read from memory
+        if (p.mode == 3) { if (threadIdx.x < 64) __atomic_thread_fence(__ATOMIC_ACQUIRE); __syncthreads(); }      // ONE wave invalidates for the block
+        else if (p.mode >= 1) __atomic_thread_fence(__ATOMIC_ACQUIRE);     // agent-scope acquire: what the neighbours wrote is re-read from memory
     }
 }
 
@@ -110,7 +112,7 @@ int main(int argc, char** argv) {
     CK(hipGetDeviceProperties(&pr, 0));
     printf("%s: %d CUs, %d resident blocks of 1024 threads per CU, cooperative launch %s; grid %d x %d = %d blocks\n", pr.name, pr.multiProcessorCount, max_blocks,
            pr.cooperativeLaunch ? "supported" : "NOT supported", nbx, nby, nb);
-    for (int mode = 0; mode <= 2; ++mode) {
+    for (int mode = 0; mode <= 3; ++mode) {
         std::vector<double> us;
         int errv = 0;
         for (int rep = 0; rep < reps + 1; ++rep) {
@@ -132,7 +134,7 @@ int main(int argc, char** argv) {
         if (!us.empty() && !errv) {
             std::sort(us.begin(), us.end());
             printf("flags mode %d (%s): %.2f us per round (median of %d; best %.2f)\n", mode,
-                   mode == 0 ? "relaxed words" : mode == 1 ? "release / acquire fences" : "fences + stores", us[us.size() / 2], (int)us.size(), us[0]);
+                   mode == 0 ? "relaxed words" : mode == 1 ? "release / acquire fences, every wave" : mode == 2 ? "fences + stores" : "release by one thread, acquire by one wave", us[us.size() / 2], (int)us.size(), us[0]);
         }
         if (errv) break;
     }
