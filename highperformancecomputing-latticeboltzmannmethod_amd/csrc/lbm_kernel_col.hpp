@@ -44,6 +44,17 @@ __device__ __forceinline__ double from_right(double v) {
 }
 __device__ __forceinline__ float from_left(float v) { return __builtin_bit_cast(float, dpp_shr1(__builtin_bit_cast(unsigned, v))); }
 __device__ __forceinline__ float from_right(float v) { return __builtin_bit_cast(float, dpp_shl1(__builtin_bit_cast(unsigned, v))); }
+// The same shifts through the LDS crossbar (ds_bpermute_b32: no LDS memory is touched; `addr` = 4 x the lane to read from). A DPP move is
+// a VECTOR instruction — two per shifted fp64 value, twelve per cell and level next to ~68 of collision arithmetic — while the LDS pipe
+// of this kernel is almost idle (2.2 lane-instructions per update): round 5 measures whether moving the shifts there shortens the
+// compute-bound levels (template parameter XS of k_stepc_col). The lane that has no neighbour reads the other end of the wave instead
+// of 0: it is a cell of the region's outermost column, garbage from level 2 on either way.
+__device__ __forceinline__ double lane_read(double v, int addr) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float lane_read(float v, int addr) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v))); }
 
 // (in-kernel phase record, tools/colbench -DLBM_COL_PROF only: LBM_PROF / LBM_PROF_IDS, lbm_kernels.hpp)
 // waves per SIMD the register allocation may assume: two blocks per CU when they fit 32 waves (8 waves: four per SIMD, 128 VGPRs;
@@ -87,7 +98,9 @@ __device__ __forceinline__ bool unstable_if(const T (&f)[Q], bool valid) {
 // buffer stays double-buffered: a wave rewrites buffer L & 1 at level L + 2, after it has seen both neighbours at level L + 1, i.e.
 // after they have finished the reads of level L. Every wave is resident (one block), so the waits are bounded by construction.
 // Measured in tools/colbench (profiles/r05/README.md); the library builds SYNC 0.
-template <typename T, int R, int NW, int D, bool NT, int AR = AR_STRICT, int SYNC = 0>
+// XS (round 5): which of the six x-shifted values of a cell and level travel through the LDS crossbar instead of DPP moves: 0 none (the
+// library's kernels), 1 all six, 2 the four diagonal ones (f5, f6, f7, f8), 3 two of them (f7, f8).
+template <typename T, int R, int NW, int D, bool NT, int AR = AR_STRICT, int SYNC = 0, int XS = 0>
 __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_col(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int H = R * NW, HW = D - 1, OW = 64 - 2 * HW, OH = H - 2 * HW, LW = 64 + 2;
     static_assert(D >= 2 && OH >= 1 && R >= 2, "(D <= GR on a strip: its ghost rows go GR deep — the host's business)");
@@ -99,6 +112,13 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
     [[maybe_unused]] __shared__ int wave_level[SYNC ? NW : 1];
     const int lane = (int)threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    [[maybe_unused]] const int a_left = ((lane + 63) & 63) * 4, a_right = ((lane + 1) & 63) * 4;
+    auto left14 = [&](T v) { if constexpr (XS == 1) return lane_read(v, a_left); else return from_left(v); };        // f1 / f3
+    auto right14 = [&](T v) { if constexpr (XS == 1) return lane_read(v, a_right); else return from_right(v); };
+    auto left56 = [&](T v) { if constexpr (XS == 1 || XS == 2) return lane_read(v, a_left); else return from_left(v); };      // f5 / f6 (carried up the rows)
+    auto right56 = [&](T v) { if constexpr (XS == 1 || XS == 2) return lane_read(v, a_right); else return from_right(v); };
+    auto left78 = [&](T v) { if constexpr (XS != 0) return lane_read(v, a_left); else return from_left(v); };                  // f8 / f7
+    auto right78 = [&](T v) { if constexpr (XS != 0) return lane_read(v, a_right); else return from_right(v); };
     if constexpr (SYNC != 0) {       // (before the early return below: every wave of the block passes this barrier or none does)
         if (lane == 0) wave_level[w] = 1;
         __syncthreads();
@@ -203,9 +223,9 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
                 const T n2 = g[j][2], n5 = g[j][5], n6 = g[j][6];       // this row's north-going values, for row j+1
                 if (ry >= L - 1 && ry <= H - L) {                       // (wave-uniform) rows outside hold garbage from here on
                 T f[Q];
-                f[0] = g[j][0]; f[1] = from_left(g[j][1]); f[3] = from_right(g[j][3]);
+                f[0] = g[j][0]; f[1] = left14(g[j][1]); f[3] = right14(g[j][3]);
                 f[2] = p2; f[5] = p5; f[6] = p6;
-                if (j < R - 1) { f[4] = g[j + 1][4]; f[7] = from_right(g[j + 1][7]); f[8] = from_left(g[j + 1][8]); }
+                if (j < R - 1) { f[4] = g[j + 1][4]; f[7] = right78(g[j + 1][7]); f[8] = left78(g[j + 1][8]); }
                 else { f[4] = xb[wa][3][1 + lane]; f[7] = xb[wa][4][2 + lane]; f[8] = xb[wa][5][lane]; }   // (read here, not after the barrier: six registers fewer are live across the rows below; the buffer is not rewritten before this wave has passed the next barrier)
                 const bool valid = lane_ok;
                 const int y = Yr + ry, yg = a.y_start + y;
@@ -243,7 +263,7 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
                     }
                 }
                 }
-                if (j < R - 1) { p2 = n2; p5 = from_left(n5); p6 = from_right(n6); }   // row j+1 pulls them from this row
+                if (j < R - 1) { p2 = n2; p5 = left56(n5); p6 = right56(n6); }   // row j+1 pulls them from this row
             }
             if (badl) atomicMin(a.unstable_t, *a.t_base + a.t + L - 1);
             LBM_PROF(b, NW, w, L);
