@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (on the GPU box, from the repo root): tools/profile_round5.sh OUTDIR [skip-traffic]
+# Usage (on the GPU box, from the repo root): [ONLY="names"] tools/profile_round5.sh OUTDIR [skip-traffic]
 # Round-5 record of the binary in the tree, in the order that keeps every committed line reproducible (round 4
 # wrote the per-grid lines with --no-live-pmc BEFORE the new traffic table was in place, so all six carried `stale: true`):
 #  (1) profiles/traffic.json FIRST — live counter passes of every fused candidate of every BASELINE.json grid (tools/collect_live_traffic.py)
@@ -22,7 +22,9 @@ if [ "$2" != "skip-traffic" ]; then
 fi
 B="bench.py --no-cpu-baseline --no-other-arith --no-f32-variant"
 run() {
-  name=$1; shift; mkdir -p "$OUT/$name"
+  name=$1; shift
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $name "; then return 0; fi      # ONLY="c3_f64_contracted c2_1024x256_f64": a part of the record per call
+  mkdir -p "$OUT/$name"
   say "$name: bench line with live passes"
   python3 $B "$@" > "$OUT/$name/bench_line.json" 2> "$OUT/$name/bench_line.err"
   say "$name: kernel trace"
@@ -37,8 +39,10 @@ run c2_1024x256_f64 --steps 12000 --warmup 1200 --nx 1024 --ny 256 --re 100
 run c4_8192x2048_f64 --steps 1500 --warmup 150 --nx 8192 --ny 2048
 run c3_f32 --steps 6000 --warmup 600 --precision f32
 run c5_16384x4096_f32 --steps 600 --warmup 60 --precision f32 --nx 16384 --ny 4096
-say "default bench line"
-python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-say "driver-style bench line"
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_style.json" 2> "$OUT/bench_driver_style.err"
+if [ -z "$ONLY" ] || echo " $ONLY " | grep -q " bench "; then
+  say "default bench line"
+  python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+  say "driver-style bench line"
+  python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_style.json" 2> "$OUT/bench_driver_style.err"
+fi
 say done
