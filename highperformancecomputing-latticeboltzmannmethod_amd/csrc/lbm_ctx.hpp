@@ -308,9 +308,52 @@ struct lbm_ctx {
     double* d_halo = nullptr;  // 4 faces-in-flight x [HR1][9][nx] doubles
 };
 
-// hipStreamSynchronize with a bound: polls hipStreamQuery (busy for the first 200 us — the end of a timed window must not pay a
-// scheduler quantum — then yielding, then sleeping 100 us at a time) and gives up with LBM_ERR_TIMEOUT after the context's
-// "wait_timeout_ms" (LBM_WAIT_TIMEOUT_MS, five minutes), saying which stream of which strip was still busy at which iteration.
+// A wait that cannot be bounded can at least name itself: a blocking runtime call registers here, and a watchdog thread (started with the
+// first registration, one per process, never joined) reports every wait that outlives the default bound — ONE line on stderr and in the
+// LBM_TRACE file, with the strip, the stream and the iteration the queue reaches. The call itself is not interrupted.
+struct Watchdog {
+    struct Item { unsigned long id; char text[200]; std::chrono::steady_clock::time_point t0; bool reported; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Item> items;
+    unsigned long next = 1;
+    bool started = false;
+    static Watchdog& get() { static Watchdog* w = new Watchdog(); return *w; }       // (leaked on purpose: the thread outlives static destruction)
+    unsigned long enter(const char* text) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!started) { started = true; std::thread([this] { loop(); }).detach(); }
+        Item it{next++, "", std::chrono::steady_clock::now(), false};
+        snprintf(it.text, sizeof(it.text), "%s", text);
+        items.push_back(it);
+        return it.id;
+    }
+    void leave(unsigned long id) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t k = 0; k < items.size(); ++k) if (items[k].id == id) { items.erase(items.begin() + (long)k); break; }
+    }
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait_for(lk, std::chrono::milliseconds(500));
+            const auto now = std::chrono::steady_clock::now();
+            for (Item& it : items) {
+                const long ms = (long)std::chrono::duration_cast<std::chrono::milliseconds>(now - it.t0).count();
+                if (!it.reported && ms > default_wait_timeout_ms()) {
+                    it.reported = true;
+                    fprintf(stderr, "lbm_hip: STALL: %s — waiting for %ld ms (pid %d)\n", it.text, ms, (int)getpid());
+                    fflush(stderr);
+                    lbm_trace("STALL", "%s — waiting for %ld ms", it.text, ms);
+                }
+            }
+        }
+    }
+};
+
+// hipStreamSynchronize with a bound: polls hipStreamQuery (busy for the first 200 us, then yielding, then sleeping 100 us at a time) and
+// gives up with LBM_ERR_TIMEOUT after `limit_ms`, saying which stream of which strip was still busy at which iteration. Used where the
+// time does not matter (the drains of lbm_initialise / lbm_destroy: default bound) and by lbm_sync when the caller has set
+// "wait_timeout_ms". lbm_sync's DEFAULT is the blocking hipStreamSynchronize under the watchdog above: polling the stream while a short
+// timed window runs costs throughput (round 4 measured 147.8 against 153.9 GLUPS in the driver's 20-step window, profiles/r04/README.md §3).
 inline int wait_stream(const lbm_ctx* c, hipStream_t s, const char* what) {
     const long limit_ms = c->wait_timeout_ms > 0 ? c->wait_timeout_ms : default_wait_timeout_ms();
     const auto t0 = std::chrono::steady_clock::now();
@@ -330,4 +373,14 @@ inline int wait_stream(const lbm_ctx* c, hipStream_t s, const char* what) {
         else if (us > 200) std::this_thread::yield();
     }
 }
-
+// the blocking form, named by the watchdog if it outlives the default bound
+inline int sync_stream_blocking(const lbm_ctx* c, hipStream_t s, const char* what) {
+    char text[200];
+    snprintf(text, sizeof(text), "hipStreamSynchronize(%s) of the strip of rows %d..%d on device %d, work queued up to iteration %d", what, c->p.y_start,
+             c->p.y_start + c->nyl, c->device, c->steps_done);
+    const unsigned long id = Watchdog::get().enter(text);
+    const hipError_t e = hipStreamSynchronize(s);
+    Watchdog::get().leave(id);
+    if (e != hipSuccess) return fail(LBM_ERR_HIP, "hipStreamSynchronize(%s) -> %s", what, hipGetErrorString(e));
+    return LBM_OK;
+}

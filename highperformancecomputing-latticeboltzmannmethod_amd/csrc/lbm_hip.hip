@@ -281,8 +281,10 @@ int lbm_step(lbm_ctx* c, int nsteps, int output_frequency) {
 int lbm_sync(lbm_ctx* c) {
     if (!c) return fail(LBM_ERR_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
-    int rc = wait_stream(c, c->stream, "compute stream");
-    if (!rc) rc = wait_stream(c, c->comm_stream, "exchange stream");
+    // bounded (a poll) where the caller has set "wait_timeout_ms"; else the blocking call, which a watchdog names if it stalls (lbm_ctx.hpp)
+    auto wait = [&](hipStream_t s, const char* what) { return c->wait_timeout_ms > 0 ? wait_stream(c, s, what) : sync_stream_blocking(c, s, what); };
+    int rc = wait(c->stream, "compute stream");
+    if (!rc) rc = wait(c->comm_stream, "exchange stream");
     return rc;
 }
 

@@ -564,10 +564,11 @@ def test_a_stalled_strip_turns_into_a_timeout_that_names_it(lbm):
 
 
 @pytest.mark.timeout(120)
-def test_lbm_sync_is_bounded(lbm):
-    """lbm_sync polls the streams instead of blocking in hipStreamSynchronize: with a bound far below the queued work (a few
-    thousand iterations of the headline grid) it returns LBM_ERR_TIMEOUT naming the stream and the iteration the queue reaches;
-    with the default bound the same call then drains the queue."""
+def test_lbm_sync_is_bounded_on_request(lbm):
+    """With "wait_timeout_ms" set, lbm_sync polls the streams instead of blocking in hipStreamSynchronize: with a bound far below the
+    queued work (a few thousand iterations of the headline grid) it returns LBM_ERR_TIMEOUT naming the stream and the iteration the
+    queue reaches; with the bound lifted the same call drains the queue through the blocking path (the default: polling a stream while a
+    short timed window runs costs throughput, profiles/r04/README.md §3 — a watchdog thread names a blocking wait that stalls)."""
     with lbm.Context(4096, 1024, inlet_velocity=0.0651, options=dict(PLANS["fast-rowil-col6"], trailing_pair=1)) as c:
         c.initialise()
         c.sync()
@@ -578,6 +579,23 @@ def test_lbm_sync_is_bounded(lbm):
         c.set_option("wait_timeout_ms", 0)
         c.sync()
         assert c.steps_done == 3000 and c.first_unstable_step() == -1
+
+
+@pytest.mark.timeout(180)
+def test_a_blocking_wait_that_stalls_is_named_by_the_watchdog(tmp_path):
+    """lbm_sync's default is the blocking hipStreamSynchronize; a wait that outlives the bound (LBM_WAIT_TIMEOUT_MS, here 300 ms against
+    ~0.5 s of queued work) is not interrupted but NAMED: one STALL line on stderr and in the LBM_TRACE file, with the strip, the stream
+    and the iteration — silence can no longer be the only record of a run that hangs in the runtime."""
+    import subprocess
+    import sys
+    trace = tmp_path / "trace.txt"
+    code = (f"import importlib, sys; sys.path.insert(0, {ROOT!r}); lbm = importlib.import_module({PKG!r})\n"
+            "with lbm.Context(4096, 1024, inlet_velocity=0.0651, options=dict(tune=0, layout=1, nt=1, alternate=0, fuse=1, arith=1)) as c:\n"
+            "    c.initialise(); c.sync(); c.step(12000, 0); c.sync(); assert c.first_unstable_step() == -1\n")
+    out = subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LBM_TRACE=str(trace), LBM_WAIT_TIMEOUT_MS="300"), timeout=170,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert "lbm_hip: STALL: hipStreamSynchronize(compute stream) of the strip of rows 0..1024 on device 0, work queued up to iteration 12000" in out.stderr, out.stderr[-500:]
+    assert any(" STALL " in ln for ln in trace.read_text().splitlines())
 
 
 @pytest.mark.timeout(180)
