@@ -44,17 +44,6 @@ __device__ __forceinline__ double from_right(double v) {
 }
 __device__ __forceinline__ float from_left(float v) { return __builtin_bit_cast(float, dpp_shr1(__builtin_bit_cast(unsigned, v))); }
 __device__ __forceinline__ float from_right(float v) { return __builtin_bit_cast(float, dpp_shl1(__builtin_bit_cast(unsigned, v))); }
-// The same shifts through the LDS crossbar (ds_bpermute_b32: no LDS memory is touched; `addr` = 4 x the lane to read from). A DPP move is
-// a VECTOR instruction — two per shifted fp64 value, twelve per cell and level next to ~68 of collision arithmetic — while the LDS pipe
-// of this kernel is almost idle (2.2 lane-instructions per update): round 5 measures whether moving the shifts there shortens the
-// compute-bound levels (template parameter XS of k_stepc_col). The lane that has no neighbour reads the other end of the wave instead
-// of 0: it is a cell of the region's outermost column, garbage from level 2 on either way.
-__device__ __forceinline__ double lane_read(double v, int addr) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)(u >> 32));
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ float lane_read(float v, int addr) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v))); }
 
 // (in-kernel phase record, tools/colbench -DLBM_COL_PROF only: LBM_PROF / LBM_PROF_IDS, lbm_kernels.hpp)
 // waves per SIMD the register allocation may assume: two blocks per CU when they fit 32 waves (8 waves: four per SIMD, 128 VGPRs;
@@ -91,16 +80,12 @@ __device__ __forceinline__ bool unstable_if(const T (&f)[Q], bool valid) {
 // load together and compute together instead of filling each other's gaps, which the dispatcher's staggered hand-out gives
 // for free; the loop also costs registers (every loop-invariant scalar offset wants an SGPR for the whole kernel: 106 SGPRs,
 // > 100 spilled, 164 -> 142 GLUPS even when launched one block per tile). Gone.
-// SYNC (round 5): how the waves of a block meet between two levels. 0: one __syncthreads() per level (the library's
-// kernels). 1: NEIGHBOUR FLAGS — a wave publishes the level it has written its six exchange values for in an LDS word and waits for
-// the words of the wave below and the wave above only, so a block's fast waves start level 2 while its slowest wave still waits
-// for its level-1 loads (the phase record of round 4: ~11 us of a block's 21 us are spent behind the first barrier). The exchange
-// buffer stays double-buffered: a wave rewrites buffer L & 1 at level L + 2, after it has seen both neighbours at level L + 1, i.e.
-// after they have finished the reads of level L. Every wave is resident (one block), so the waits are bounded by construction.
-// Measured in tools/colbench (profiles/r05/README.md); the library builds SYNC 0.
-// XS (round 5): which of the six x-shifted values of a cell and level travel through the LDS crossbar instead of DPP moves: 0 none (the
-// library's kernels), 1 all six, 2 the four diagonal ones (f5, f6, f7, f8), 3 two of them (f7, f8).
-template <typename T, int R, int NW, int D, bool NT, int AR = AR_STRICT, int SYNC = 0, int XS = 0>
+// Round 5 measured two more forms of this kernel and dropped both (profiles/r05/README.md §2-3; the code is archived as a patch in
+// profiles/r05/archive/): the waves of a block meeting through NEIGHBOUR FLAGS in LDS instead of one barrier per level (bit-exact; a
+// wave's first wait shrinks, but a CU's slot frees only with a block's last wave: residency 1.63 -> 1.47 blocks per CU, -5 %), and the
+// x-shifts through the LDS CROSSBAR (ds_bpermute_b32) instead of DPP moves (bit-exact; -1..3 %: the crossbar's latency sits in every
+// row's dependency chain and vector issue is not the binding resource at the margin).
+template <typename T, int R, int NW, int D, bool NT, int AR = AR_STRICT>
 __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_col(const KArgs<T> a, const K2Extra<T> e) {
     constexpr int H = R * NW, HW = D - 1, OW = 64 - 2 * HW, OH = H - 2 * HW, LW = 64 + 2;
     static_assert(D >= 2 && OH >= 1 && R >= 2, "(D <= GR on a strip: its ghost rows go GR deep — the host's business)");
@@ -109,20 +94,8 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
     // that are garbage anyway: round 4 dropped the two phantom slots, 63 -> 51 KB at 8 fp64 waves, so that 12 waves fit two
     // blocks per CU); one pad column on each side for the diagonal reads at lane -/+ 1
     __shared__ T xbuf[2][NW][6][LW];
-    [[maybe_unused]] __shared__ int wave_level[SYNC ? NW : 1];
     const int lane = (int)threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    [[maybe_unused]] const int a_left = ((lane + 63) & 63) * 4, a_right = ((lane + 1) & 63) * 4;
-    auto left14 = [&](T v) { if constexpr (XS == 1) return lane_read(v, a_left); else return from_left(v); };        // f1 / f3
-    auto right14 = [&](T v) { if constexpr (XS == 1) return lane_read(v, a_right); else return from_right(v); };
-    auto left56 = [&](T v) { if constexpr (XS == 1 || XS == 2) return lane_read(v, a_left); else return from_left(v); };      // f5 / f6 (carried up the rows)
-    auto right56 = [&](T v) { if constexpr (XS == 1 || XS == 2) return lane_read(v, a_right); else return from_right(v); };
-    auto left78 = [&](T v) { if constexpr (XS != 0) return lane_read(v, a_left); else return from_left(v); };                  // f8 / f7
-    auto right78 = [&](T v) { if constexpr (XS != 0) return lane_read(v, a_right); else return from_right(v); };
-    if constexpr (SYNC != 0) {       // (before the early return below: every wave of the block passes this barrier or none does)
-        if (lane == 0) wave_level[w] = 1;
-        __syncthreads();
-    }
     const int nbx = (a.nx + OW - 1) / OW, nby = (a.y_cnt + OH - 1) / OH + (a.y_cnt2 + OH - 1) / OH, nb = nbx * nby;
     int b = blockIdx.x;
     { const int per = (int)gridDim.x >> 3; b = (b & 7) * per + (b >> 3); }                   // gridDim.x is a multiple of 8
@@ -205,14 +178,7 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
             const int wb = w > 0 ? w - 1 : 0, wa = w + 1 < NW ? w + 1 : NW - 1;
             xb[w][0][1 + lane] = g[R - 1][2]; xb[w][1][1 + lane] = g[R - 1][5]; xb[w][2][1 + lane] = g[R - 1][6];
             xb[w][3][1 + lane] = g[0][4];     xb[w][4][1 + lane] = g[0][7];     xb[w][5][1 + lane] = g[0][8];
-            if constexpr (SYNC == 0) __syncthreads();
-            else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the six values are in LDS ...
-                if (lane == 0) *(volatile int*)&wave_level[w] = L;                   // ... before the word that says so
-                while (__builtin_amdgcn_readfirstlane(*(volatile int*)&wave_level[wb]) < L) { if constexpr (SYNC == 1) __builtin_amdgcn_s_sleep(1); }
-                while (__builtin_amdgcn_readfirstlane(*(volatile int*)&wave_level[wa]) < L) { if constexpr (SYNC == 1) __builtin_amdgcn_s_sleep(1); }      // (SYNC 2: busy poll)
-                asm volatile("" ::: "memory");
-            }
+            __syncthreads();
             // from the wave below (its top row): f2 at x, f5 at x-1, f6 at x+1; from the wave above (its bottom row): f4, f7 at x+1, f8 at x-1
             T p2 = xb[wb][0][1 + lane], p5 = xb[wb][1][lane], p6 = xb[wb][2][2 + lane];
             bool badl = false;
@@ -223,9 +189,9 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
                 const T n2 = g[j][2], n5 = g[j][5], n6 = g[j][6];       // this row's north-going values, for row j+1
                 if (ry >= L - 1 && ry <= H - L) {                       // (wave-uniform) rows outside hold garbage from here on
                 T f[Q];
-                f[0] = g[j][0]; f[1] = left14(g[j][1]); f[3] = right14(g[j][3]);
+                f[0] = g[j][0]; f[1] = from_left(g[j][1]); f[3] = from_right(g[j][3]);
                 f[2] = p2; f[5] = p5; f[6] = p6;
-                if (j < R - 1) { f[4] = g[j + 1][4]; f[7] = right78(g[j + 1][7]); f[8] = left78(g[j + 1][8]); }
+                if (j < R - 1) { f[4] = g[j + 1][4]; f[7] = from_right(g[j + 1][7]); f[8] = from_left(g[j + 1][8]); }
                 else { f[4] = xb[wa][3][1 + lane]; f[7] = xb[wa][4][2 + lane]; f[8] = xb[wa][5][lane]; }   // (read here, not after the barrier: six registers fewer are live across the rows below; the buffer is not rewritten before this wave has passed the next barrier)
                 const bool valid = lane_ok;
                 const int y = Yr + ry, yg = a.y_start + y;
@@ -263,7 +229,7 @@ __global__ void __launch_bounds__(NW * 64, (col_waves_per_simd<NW>())) k_stepc_c
                     }
                 }
                 }
-                if (j < R - 1) { p2 = n2; p5 = left56(n5); p6 = right56(n6); }   // row j+1 pulls them from this row
+                if (j < R - 1) { p2 = n2; p5 = from_left(n5); p6 = from_right(n6); }   // row j+1 pulls them from this row
             }
             if (badl) atomicMin(a.unstable_t, *a.t_base + a.t + L - 1);
             LBM_PROF(b, NW, w, L);

@@ -80,6 +80,10 @@ int  lbm_initialise(lbm_ctx* c, int* solid_count_out);
  * Grid::exchange_ghost_cells, LBMGrid.h:249-283). */
 int  lbm_step(lbm_ctx* c, int nsteps, int output_frequency);
 
+/* Waits for everything queued on the context's two streams. Default: the blocking hipStreamSynchronize (the fastest way to wait; a
+ * watchdog thread prints one "lbm_hip: STALL: ..." line on stderr — strip, stream, iteration — if it outlives LBM_WAIT_TIMEOUT_MS, five
+ * minutes by default). With the option "wait_timeout_ms" set: a bounded poll that returns LBM_ERR_TIMEOUT instead of blocking on. The
+ * reference's counterpart is the implicit completion of every loop body (it is synchronous, LBMSolver.h:48-76). */
 int  lbm_sync(lbm_ctx* c);
 int  lbm_steps_done(const lbm_ctx* c);
 
@@ -130,7 +134,11 @@ int  lbm_comm_allreduce(lbm_ctx* c, double* vals, int n, int op);
  * The launch sequence, the exchange cadence and the overlap are those of lbm_step. Per-strip results
  * (lbm_get_macros, lbm_drain_force_log, lbm_first_unstable_step, ...) are read member by member and combined by the
  * caller (sum of forces, min of the unstable step, rows concatenated by y_start: LBMSolver.h:269-362, LBMIO.h:167-168).
- * lbm_group_refresh_halos: after lbm_load_state on every member. */
+ * lbm_group_refresh_halos: after lbm_load_state on every member.
+ * Errors: a member's failure (or LBM_ERR_TIMEOUT: a strip thread that did not reach a rendezvous within "wait_timeout_ms") makes
+ * lbm_group_step return that error on the caller with every strip thread parked again; the launch in flight was abandoned half-way,
+ * so the populations are undefined until lbm_group_initialise (or lbm_load_state + lbm_group_refresh_halos) — after a time-out the
+ * group refuses further work and is only good for lbm_destroy. */
 int  lbm_group_link(lbm_ctx** ctxs, int n, int transport);
 int  lbm_group_initialise(lbm_ctx** ctxs, int n, int* solid_total_out);
 int  lbm_group_step(lbm_ctx** ctxs, int n, int nsteps, int output_frequency);

@@ -118,6 +118,32 @@ Variant<T> col_variant(bool nt, bool alt = false, int persist = 0) {
     }};
 }
 static int g_cus = 256;
+// round 5: the waves of a block meet through neighbour flags instead of one barrier per level (k_stepc_col<.., SYNC = 1>)
+template <typename T, int R, int NW, int D, int AR, int SYNC = 1>
+Variant<T> colsync_variant(bool alt = false) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "colsync%d R=%d NW=%d D=%d %s", SYNC, R, NW, D, alt ? "alt" : "");
+    return {nm, D, [=](Lattice<T>& L) {
+        constexpr int OW = 64 - 2 * (D - 1), OH = R * NW - 2 * (D - 1);
+        const int nb = ((L.nx + OW - 1) / OW) * ((L.ny + OH - 1) / OH);
+        KArgs<T> a = L.args(L.t);
+        a.reverse = alt ? (L.cur & 1) : 0;
+        hipLaunchKernelGGL((k_stepc_col<T, R, NW, D, false, AR, SYNC>), dim3((nb + 7) / 8 * 8), dim3(NW * 64), 0, L.s, a, L.extra());
+    }, NW};
+}
+// round 5: x-shifts through the LDS crossbar (ds_bpermute) instead of DPP moves (k_stepc_col<.., XS>)
+template <typename T, int R, int NW, int D, int AR, int XS>
+Variant<T> colxs_variant(bool alt = true) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "colxs%d R=%d NW=%d D=%d %s", XS, R, NW, D, alt ? "alt" : "");
+    return {nm, D, [=](Lattice<T>& L) {
+        constexpr int OW = 64 - 2 * (D - 1), OH = R * NW - 2 * (D - 1);
+        const int nb = ((L.nx + OW - 1) / OW) * ((L.ny + OH - 1) / OH);
+        KArgs<T> a = L.args(L.t);
+        a.reverse = alt ? (L.cur & 1) : 0;
+        hipLaunchKernelGGL((k_stepc_col<T, R, NW, D, false, AR, 0, XS>), dim3((nb + 7) / 8 * 8), dim3(NW * 64), 0, L.s, a, L.extra());
+    }, NW};
+}
 template <typename T, int TX, int TY, int D, int AR>
 Variant<T> tile_variant() {
     char nm[96];
@@ -139,6 +165,14 @@ std::vector<Variant<T>> variants() {
     v.push_back(col_variant<T, 4, 8, 6, AR>(true));
     v.push_back(col_variant<T, 4, 8, 6, AR>(false));
     v.push_back(col_variant<T, 4, 8, 6, AR>(false, true));
+    v.push_back(colsync_variant<T, 4, 8, 6, AR>(false));
+    v.push_back(colsync_variant<T, 4, 8, 6, AR>(true));
+    v.push_back(colsync_variant<T, 4, 8, 7, AR>(true));
+    v.push_back(colsync_variant<T, 4, 8, 6, AR, 2>(true));
+    v.push_back(colxs_variant<T, 4, 8, 6, AR, 1>());
+    v.push_back(colxs_variant<T, 4, 8, 6, AR, 2>());
+    v.push_back(colxs_variant<T, 4, 8, 6, AR, 3>());
+    v.push_back(colxs_variant<T, 4, 8, 7, AR, 2>());
     v.push_back(col_variant<T, 4, 8, 7, AR>(false));
     v.push_back(col_variant<T, 4, 8, 7, AR>(false, true));
     v.push_back(col_variant<T, 3, 8, 5, AR>(true));

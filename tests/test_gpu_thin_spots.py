@@ -462,3 +462,23 @@ def test_the_trimmed_halo_message_is_result_invariant(lbm):
     for other in out[1:]:
         assert np.array_equal(out[0][0], other[0]) and out[0][1] == other[1]
 
+
+def test_kernel_name_is_the_kernel_that_really_runs_on_a_host_staged_strip(lbm):
+    """a strip whose halos are staged through the host carries LBM_HALO_ROWS = 6 ghost rows per exchange, so a plan of seven
+    or eight iterations per launch falls back to the three-iteration tile kernel there (plan_launch) — and lbm_kernel_name must say so,
+    because bench.py attributes time and counter bytes by that name. Whole domains and strips with a device transport keep the plan's
+    own kernel."""
+    kw = dict(inlet_velocity=0.05)
+    with lbm.Context(256, 120, y_start=40, local_ny=40, options=dict(tune=0, layout=1, nt=0, pair_ty=12, xcd=1, deep=9, arith=1), **kw) as strip:
+        strip.initialise()
+        assert strip.kernel_name().replace(" ", "") == "k_step3_tile<double,12,1024,1>", strip.kernel_name()
+    with lbm.Context(256, 120, options=dict(tune=0, layout=1, nt=0, pair_ty=12, xcd=1, deep=9, arith=1), **kw) as whole:
+        whole.initialise()
+        assert whole.kernel_name().replace(" ", "") == "k_stepc_col<double,4,8,7,false,1>", whole.kernel_name()
+    with lbm.Context(256, 40, options=dict(tune=0, layout=1, nt=0, pair_ty=12, xcd=1, deep=9, arith=1, loopback=1), **kw) as loop:
+        loop.initialise()
+        assert loop.kernel_name().replace(" ", "") == "k_stepc_col<double,4,8,7,false,1>", loop.kernel_name()
+    with lbm.Context(256, 120, y_start=40, local_ny=40, options=dict(tune=0, layout=1, nt=1, pair_ty=12, xcd=1, deep=7, arith=1), **kw) as six:
+        six.initialise()       # six iterations per launch fit the six staged rows: the register kernel stays
+        assert six.kernel_name().replace(" ", "") == "k_stepc_col<double,4,8,6,true,1>", six.kernel_name()
+
