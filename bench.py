@@ -410,6 +410,7 @@ def main():
         sys.exit(f"simulation unstable at timestep {bad}: result invalid")
     # what ran in the timed region (the parity pass below initialises the context again)
     kernel, plan_used, schedule_used = ctx.kernel_name(), ctx.plan(), ctx.strip_schedule()
+    plan_pairs = " ".join(f"{k}={v}" for k, v in ctx.plan_options().items())      # `--set tune=0 --set <pair> ...` reproduces the plan in another run
     arith_id = 1 if args.arith == "contracted" else 0
     roof = roofline_of(lbm, ctx, nx, local_ny, args.precision, kernel_ms, launches, iterations, args.steps, arith_id,
                        live=(world == 1 and not args.no_live_pmc), re_number=args.re) if rank == 0 else None
@@ -469,7 +470,7 @@ def main():
                                       "strict IEEE, operation by operation (populations bit-identical to the CPU oracle)"),
                        "halo": "none" if world == 1 else f"RCCL send/recv of {hr} edge rows x 9 populations per face (one contiguous message "
                                                           f"of {hr * 9} sub-rows); schedule: {schedule_used}",
-                       "kernel": kernel, "plan": plan_used, "build_id": lbm.build_id(),
+                       "kernel": kernel, "plan": plan_used, "plan_options": plan_pairs, "build_id": lbm.build_id(),
                        "runtime": {"rccl": versions["rccl"], "hip_runtime": versions["hip_runtime"], "hip_driver": versions["hip_driver"],
                                    "torch_loaded": torch is not None}},
             "roofline": roof,

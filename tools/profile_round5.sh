@@ -27,8 +27,11 @@ run() {
   mkdir -p "$OUT/$name"
   say "$name: bench line with live passes"
   python3 $B "$@" > "$OUT/$name/bench_line.json" 2> "$OUT/$name/bench_line.err"
-  say "$name: kernel trace"
-  ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$OUT/$name/stats" -o s --output-format csv -- python3 "$GRAFT_REPO_ROOT/"$B --no-live-pmc "$@" > "$GRAFT_REPO_ROOT/$OUT/$name/stats.log" 2>&1 )
+  # the traced run is pinned to the plan the line above measured (finalists 1-2 % apart flip between two runs: round 5's first record
+  # paired a line on the nt-load plan with the trace of an nt-store run)
+  PIN=$(python3 -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(' '.join('--set ' + kv for kv in ['tune=0'] + d['config']['plan_options'].split()))" "$OUT/$name/bench_line.json")
+  say "$name: kernel trace ($PIN)"
+  ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$OUT/$name/stats" -o s --output-format csv -- python3 "$GRAFT_REPO_ROOT/"$B --no-live-pmc $PIN "$@" > "$GRAFT_REPO_ROOT/$OUT/$name/stats.log" 2>&1 )
   cp "$OUT/$name"/stats/*kernel_stats.csv "$OUT/$name/kernel_stats.csv"
   rm -rf "$OUT/$name/stats" "$OUT/$name/stats.log"
   say "$name: $(cut -c1-90 $OUT/$name/bench_line.json)"
