@@ -289,6 +289,7 @@ struct lbm_ctx {
     int debug_fault_launch = -1, debug_fault_point = 0, debug_fault_stall_ms = 0;
     Choreo* rec = nullptr;        // dry run (lbm_debug_choreography): record what would be queued, call no runtime function
     int debug_old_edge_band = 0;  // TEST ONLY: the edge-band height as it was before round 4's fix (the detector must flag it)
+    int debug_skip_pull_wait = 0; // TEST ONLY: a launch does not wait for its neighbours' pulls before overwriting its edge rows (the detector must flag it)
     bool owns_comm = true;
     std::shared_ptr<GroupPool> pool;   // the group's host threads (shared by its members)
     int edge_rows[2] = {0, 0};   // edge-band heights of the launch in flight (issue_before -> issue_after)

@@ -645,6 +645,7 @@ int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     else if (k == "debug_fault_point") { if (value < 0 || value > 2) return fail(LBM_ERR_ARG, "debug_fault_point must be 0, 1 or 2"); c->debug_fault_point = (int)value; }
     else if (k == "debug_fault_stall_ms") c->debug_fault_stall_ms = (int)value;
     else if (k == "debug_old_edge_band") c->debug_old_edge_band = (int)value ? 1 : 0;      // TEST ONLY: see lbm_ctx
+    else if (k == "debug_skip_pull_wait") c->debug_skip_pull_wait = (int)value ? 1 : 0;    // TEST ONLY: see lbm_ctx
     else if (k == "graph") { if (value < 0 || value > 2) return fail(LBM_ERR_ARG, "graph must be 0, 1 or 2"); c->use_graph = (int)value; }
     else if (k == "loopback") c->loopback = (int)value;   // 0 off, 1 device copies, 2 RCCL self send/recv
     else if (k == "pair_ty") { if (value != 8 && value != 12) return fail(LBM_ERR_ARG, "pair_ty must be 8 or 12"); c->pair_ty = (int)value; }
@@ -758,6 +759,32 @@ int lbm_debug_face_runs(int hr, int trim, int south_block, int* runs10) {
     const FaceRuns r = face_runs(hr, trim != 0, south_block != 0);
     for (int k = 0; k < r.n; ++k) { runs10[2 * k] = r.off[k]; runs10[2 * k + 1] = r.cnt[k]; }
     return r.n;
+}
+
+/* TEST HOOK (no device needed): the host threads of a group (GroupPool, csrc/lbm_ctx.hpp) on a dummy job of `rounds` rounds with one
+ * rendezvous each. Strip `fail_strip` reports an injected error in round `fail_round`; strip `stall_strip` sleeps `stall_ms` before
+ * the rendezvous of round `stall_round` (-1: nobody). The job runs `repeat` times on the same pool. Returns what the LAST run returned
+ * (LBM_OK / the injected LBM_ERR_HIP / LBM_ERR_TIMEOUT / "timed out earlier"); *rendezvous_out = rendezvous strip 0 passed in the last run. */
+int lbm_debug_group_pool(int n, int rounds, int fail_strip, int fail_round, int stall_strip, int stall_round, int stall_ms, long timeout_ms, int repeat,
+                         int* rendezvous_out) {
+    if (n < 2 || n > 64 || rounds < 1 || repeat < 1) return fail(LBM_ERR_ARG, "bad argument");
+    GroupPool pool(n);
+    auto passed = std::make_shared<std::atomic<int>>(0);
+    int rc = LBM_OK;
+    for (int rep = 0; rep < repeat; ++rep) {
+        passed->store(0);
+        const bool last = rep + 1 == repeat;
+        rc = pool.run([=](GroupPool::State& P, int i) {
+            for (int r = 0; r < rounds; ++r) {
+                if (last && i == fail_strip && r == fail_round) P.report(fail(LBM_ERR_HIP, "injected fault: strip %d, round %d", i, r), g_err);
+                if (last && i == stall_strip && r == stall_round) std::this_thread::sleep_for(std::chrono::milliseconds(stall_ms));
+                if (P.arrive(i, r, 1)) return;
+                if (i == 0) passed->fetch_add(1);
+            }
+        }, timeout_ms);
+    }
+    if (rendezvous_out) *rendezvous_out = passed->load();
+    return rc;        // (~GroupPool: waits, bounded, for a straggler and joins; a thread that never comes back is detached)
 }
 
 /* TEST HOOK (no device needed): dry run of the launch choreography of a strip run and its check (csrc/lbm_choreo.inc.hpp). */

@@ -425,6 +425,7 @@ int issue_before(lbm_ctx* c, const Launch& L) {
     }
     hipStream_t es = exchange_stream(c);
     auto wait_for_neighbour_pulls = [&](hipStream_t s) -> int {   // group / peer: my edge rows of buf[dst] may still be being read
+        if (c->debug_skip_pull_wait) return LBM_OK;               // (TEST ONLY: the dry-run checker must name the race this leaves)
         for (lbm_ctx* nb : {c->nb_south, c->nb_north})
             if (nb && c->group_transport == 0 && nb->comm_issued) QCHK(q_wait(c, s, nb, nb->ev_comm));
         return LBM_OK;

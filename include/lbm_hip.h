@@ -241,6 +241,14 @@ int lbm_debug_face_runs(int hr, int trim, int south_block, int* runs10);
 /* Test hook, callable without a device: the candidate plans lbm_initialise would time on a whole-domain context of this grid
  * (csrc/lbm_plan.hpp), one per line: "name|lbm_set_option pairs|dominant kernel|iterations per launch". */
 int lbm_debug_plan_candidates(int nx, int ny, int precision, int arith, int num_cus, char* out, int cap);
+/* Test hook, callable without a device: the host threads that drive the strips of an in-process group (csrc/lbm_ctx.hpp GroupPool) on a
+ * dummy job of `rounds` rounds with one rendezvous each, `repeat` times on one pool; in the last run strip `fail_strip` reports an
+ * injected error in round `fail_round` and strip `stall_strip` sleeps `stall_ms` before the rendezvous of round `stall_round` (-1:
+ * nobody). Returns what the last run returned: LBM_OK, the injected LBM_ERR_HIP (every thread left at the same rendezvous), or
+ * LBM_ERR_TIMEOUT naming the strip that was waited for (bound: timeout_ms; 0 = LBM_WAIT_TIMEOUT_MS). *rendezvous_out = rendezvous strip
+ * 0 passed in the last run. The reference's counterpart are the implicit barriers of its OpenMP regions (LBMSolver.h:87,131). */
+int lbm_debug_group_pool(int n, int rounds, int fail_strip, int fail_round, int stall_strip, int stall_round, int stall_ms, long timeout_ms, int repeat,
+                         int* rendezvous_out);
 /* Test hook, callable without a device: a DRY RUN of the launch choreography of a strip run and its check (csrc/lbm_choreo.inc.hpp). The
  * functions that issue a launch group (plan_launch, issue_before, the exchanges, issue_after) run on contexts without a device and
  * record every kernel (with the rows it writes and, through its depth, reads), event record, cross-stream wait, copy, send and receive;

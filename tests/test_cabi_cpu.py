@@ -145,3 +145,32 @@ def test_the_trimmed_halo_message_is_exactly_what_the_receiver_reads(pkg):
             assert got == want, (hr, south_block, sorted(want - got), sorted(got - want))
             assert lib.lbm_debug_face_runs(hr, 0, south_block, out) == 1 and (out[0], out[1]) == (0, 9 * hr)
 
+
+def test_group_threads_rendezvous_is_bounded_and_names_the_straggler(pkg):
+    """VERDICT r04 #1, on the CPU: the host threads of an in-process group (GroupPool: one per strip, three rendezvous per launch) on a
+    dummy job, through lbm_debug_group_pool. (a) a clean job passes every rendezvous, again and again on the same pool; (b) a strip that
+    reports an error between two rendezvous makes every thread leave at the SAME rendezvous (none is left waiting) and the caller gets the
+    strip's error; (c) a strip that stalls turns into LBM_ERR_TIMEOUT within the bound, naming it and where it was last seen — rounds 3-4
+    waited on a std::barrier without a time-out; (d) tearing the pool down after a time-out waits for the straggler instead of hanging."""
+    import time
+    lib = ctypes.CDLL(pkg.lib_path())
+    lib.lbm_debug_group_pool.argtypes = [ctypes.c_int] * 7 + [ctypes.c_long, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    lib.lbm_last_error.restype = ctypes.c_char_p
+    passed = ctypes.c_int()
+
+    def pool(n, rounds, fail=(-1, -1), stall=(-1, -1, 0), timeout_ms=0, repeat=1):
+        rc = lib.lbm_debug_group_pool(n, rounds, fail[0], fail[1], stall[0], stall[1], stall[2], timeout_ms, repeat, ctypes.byref(passed))
+        return rc, passed.value, (lib.lbm_last_error().decode() if rc else "")
+
+    assert pool(8, 300, repeat=5) == (0, 300, "")
+    assert pool(2, 50) == (0, 50, "") and pool(5, 7, repeat=3) == (0, 7, "")
+    rc, done, msg = pool(6, 40, fail=(3, 17), repeat=2)          # the first run of the pool is clean, the second fails in round 17
+    assert rc == -2 and done == 17 and "injected fault: strip 3, round 17" in msg
+    t0 = time.time()
+    rc, done, msg = pool(4, 20, stall=(2, 9, 1500), timeout_ms=200)
+    assert rc == -5 and done == 9, (rc, done, msg)
+    assert "waited 200 ms at rendezvous 1 of launch 9 of this call for: strip 2 (last seen at rendezvous 1 of launch 8)" in msg, msg
+    assert 0.2 <= time.time() - t0 < 3.0          # the bound, then the teardown waits for the straggler's 1.5 s sleep: no hang, no crash
+    rc, done, msg = pool(3, 5, stall=(0, 2, 600), timeout_ms=150)      # the CALLER's own strip is the slow one: the others time out on it
+    assert rc == -5 and "for: strip 0 (last seen at rendezvous 1 of launch 1)" in msg, msg
+

@@ -113,3 +113,19 @@ def test_a_frame_that_is_not_refreshed_is_stale(dry):
     ghost rows that still hold the previous exchange's iteration — STALE, named with the launch that read them."""
     rc, text = dry(256, 384, [(128, 128)], 2, dict(tune=0, nt=1, xcd=1, overlap=0, deep_halo=1, deep=7, skip_exchange=1), [(20, 0)])
     assert rc > 0 and "STALE strip 0 buffer" in text and "kernel t=6" in text, text
+
+
+def test_overwriting_edge_rows_under_a_neighbours_pull_is_flagged(dry):
+    """A second negative control (option "debug_skip_pull_wait", test only): in a group with peer copies a strip's edge rows are READ by
+    its neighbours' pulls, so before a launch overwrites them it must wait for the neighbours' ev_comm. Where launches come in pairs
+    between exchanges (three iterations per launch, one exchange per two launches) nothing else orders the two: without the wait the
+    checker names the write-after-read — the neighbour's copy against the launch that rewrites the rows two launches later. (With one
+    exchange per launch on the side stream the order follows transitively from the pulls themselves, and the checker agrees: no race.)"""
+    b, ny = strips_of((100, 100, 100))
+    pairs = dict(tune=0, nt=1, xcd=1, overlap=0, deep_halo=1, fuse=3, pair_ty=12)
+    rc, text = dry(256, ny, b, 0, pairs, [(40, 0)])
+    assert rc == 0, text
+    rc, text = dry(256, ny, b, 0, dict(pairs, debug_skip_pull_wait=1), [(40, 0)])
+    assert rc > 0 and "RACE strip 0 buffer" in text and "copy buf" in text and "main stream: kernel" in text, text
+    every = dict(tune=0, nt=1, xcd=1, overlap=1, deep_halo=1, deep=7, arith=1)
+    assert dry(256, ny, b, 0, dict(every, debug_skip_pull_wait=1), [(40, 0)])[0] == 0
