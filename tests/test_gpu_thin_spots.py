@@ -33,22 +33,25 @@ def moments(aos):
     return rho, (f * cx).sum(axis=2) / rho, (f * cy).sum(axis=2) / rho
 
 
-def test_production_strip_rule_at_c4_size_8192x2048(lbm):
-    """Group(8192, 2048, 8) with options=None: the rule's own pick for 256-row strips (k_stepc_col, six iterations per launch, ONE
+@pytest.mark.parametrize("arith", [0, 1])
+def test_production_strip_rule_at_c4_size_8192x2048(lbm, arith):
+    """Group(8192, 2048, 8) with no plan options: the rule's own pick for 256-row strips (k_stepc_col, six iterations per launch, ONE
     exchange per launch, schedule and store policy as measured) for 66 iterations + a force output == the whole domain bit for
-    bit. (Replaces Grid::exchange_ghost_cells, /root/reference/include/LBMGrid.h:249-283, between the strips.)"""
+    bit — in strict arithmetic and (round 5) in the CONTRACTED arithmetic an 8-GPU bench line would run.
+    (Replaces Grid::exchange_ghost_cells, /root/reference/include/LBMGrid.h:249-283, between the strips.)"""
     nx, ny, steps, of = 8192, 2048, 66, 30
     kw = dict(inlet_velocity=0.03255208)
-    with lbm.Context(nx, ny, **kw) as whole:
+    opts = dict(arith=1) if arith else None
+    with lbm.Context(nx, ny, options=opts, **kw) as whole:
         assert whole.initialise() == 32681
         whole.step(steps, of)
         assert whole.first_unstable_step() == -1
         w_fn, w_log = whole.populations("f_next"), whole.drain_force_log()
-    with lbm.Group(nx, ny, 8, options=None, **kw) as g:
+    with lbm.Group(nx, ny, 8, options=opts, **kw) as g:
         assert g.initialise() == 32681
         plans = [m.plan() for m in g.ctxs]
         assert all("6-step 64x32 in registers" in p for p in plans), plans
-        assert all(m.kernel_name().startswith("k_stepc_col<double,2,12,") for m in g.ctxs)
+        assert all(m.kernel_name().startswith("k_stepc_col<double,4,8," if arith else "k_stepc_col<double,2,12,") for m in g.ctxs)
         schedule = g.ctxs[0].strip_schedule()
         g.step(steps, of)
         assert g.first_unstable_step() == -1
@@ -57,21 +60,24 @@ def test_production_strip_rule_at_c4_size_8192x2048(lbm):
     assert [r[0] for r in log] == [r[0] for r in w_log] == [0, 30, 60]
     for (t, fx, fy), (_, wx, wy) in zip(log, w_log):      # partial sums of the strips are added in another order
         assert abs(fx - wx) <= 1e-13 * max(1.0, abs(wx)) and abs(fy - wy) <= 1e-13
-    record("c4_strips8_production_rule_66", bit_equal=True, plan=plans[0], schedule=schedule)
+    record("c4_strips8_production_rule_66" + ("_contracted" if arith else ""), bit_equal=True, plan=plans[0], schedule=schedule)
 
 
-def test_production_strip_rule_at_c5_size_16384x4096_fp32(lbm):
-    """Group(16384, 4096, 8, precision='f32') with options=None (512-row strips: k_stepc_col, one exchange per launch) for 66
+@pytest.mark.parametrize("arith", [0, 1])
+def test_production_strip_rule_at_c5_size_16384x4096_fp32(lbm, arith):
+    """Group(16384, 4096, 8, precision='f32') with no plan options (512-row strips: k_stepc_col, one exchange per launch) for 66
     iterations == the whole domain, rho / ux / uy bit for bit (the populations of 67 M cells as fp64 AoS would be 2 x 4.8 GB of
-    host memory; the snapshot is a function of the last two population states)."""
+    host memory; the snapshot is a function of the last two population states) — strict and, since round 5, contracted arithmetic
+    (what `bench.py --gpus 8 --nx 16384 --ny 4096 --precision f32` runs)."""
     nx, ny, steps = 16384, 4096, 66
     kw = dict(inlet_velocity=0.01627604, precision="f32")
-    with lbm.Context(nx, ny, **kw) as whole:
+    opts = dict(arith=1) if arith else None
+    with lbm.Context(nx, ny, options=opts, **kw) as whole:
         assert whole.initialise() == 130721
         whole.step(steps, 0)
         assert whole.first_unstable_step() == -1
         w = whole.macros()
-    with lbm.Group(nx, ny, 8, options=None, **kw) as g:
+    with lbm.Group(nx, ny, 8, options=opts, **kw) as g:
         assert g.initialise() == 130721
         plans = [m.plan() for m in g.ctxs]
         assert all("6-step 64x32 in registers" in p for p in plans), plans
@@ -80,7 +86,7 @@ def test_production_strip_rule_at_c5_size_16384x4096_fp32(lbm):
         assert g.first_unstable_step() == -1
         for a, b in zip(w, g.macros()):
             assert np.array_equal(a, b)
-    record("c5_strips8_production_rule_66", bit_equal=True, plan=plans[0])
+    record("c5_strips8_production_rule_66" + ("_contracted" if arith else ""), bit_equal=True, plan=plans[0])
 
 
 def test_one_8192x256_strip_over_rccl_replayed_from_a_graph(lbm):
