@@ -69,3 +69,20 @@ def test_the_two_eight_gpu_configs_of_baseline_json_run_end_to_end(nx, ny, preci
     assert st["parity"] == "bit-equal" and [r["rows"] for r in st["per_rank"]] == [ny // 2, ny // 2]
     assert line["value"] > 0 and line["roofline"]["algorithmic_bytes_per_launch"] > 0
 
+
+@pytest.mark.timeout(900)
+def test_eight_ranks_the_shape_of_the_drivers_scaling_run():
+    """The driver's scaling run ends at N = 8 (`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 ...`): the same control flow with
+    eight gloo ranks and the stand-in — one line from rank 0, eight strips of the named grid, the parity gather over eight ranks, every
+    rank leaving with rank 0's verdict."""
+    rcs, outs = run_bench("ok", world=8, grid=("64", "192"))
+    assert rcs == [0] * 8, [o[1][-500:] for o in outs]
+    lines = [l for o in outs for l in o[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["rows_per_gpu"] == 24 and line["config"]["decomposition"] == "8 row strip(s)"
+    st = line["strips"]
+    assert st["nranks"] == 8 and st["parity"] == "bit-equal" and [r["rank"] for r in st["per_rank"]] == list(range(8))
+    rcs, outs = run_bench("mismatch", world=8, grid=("64", "192"))
+    assert rcs == [3] * 8, [o[1][-300:] for o in outs]
+
