@@ -584,17 +584,17 @@ def test_lbm_sync_is_bounded_on_request(lbm):
 @pytest.mark.timeout(180)
 def test_a_blocking_wait_that_stalls_is_named_by_the_watchdog(tmp_path):
     """lbm_sync's default is the blocking hipStreamSynchronize; a wait that outlives the bound (LBM_WAIT_TIMEOUT_MS, here 300 ms against
-    ~0.5 s of queued work) is not interrupted but NAMED: one STALL line on stderr and in the LBM_TRACE file, with the strip, the stream
+    ~1.2 s of queued work) is not interrupted but NAMED: one STALL line on stderr and in the LBM_TRACE file, with the strip, the stream
     and the iteration — silence can no longer be the only record of a run that hangs in the runtime."""
     import subprocess
     import sys
     trace = tmp_path / "trace.txt"
     code = (f"import importlib, sys; sys.path.insert(0, {ROOT!r}); lbm = importlib.import_module({PKG!r})\n"
-            "with lbm.Context(4096, 1024, inlet_velocity=0.0651, options=dict(tune=0, layout=1, nt=1, alternate=0, fuse=1, arith=1)) as c:\n"
-            "    c.initialise(); c.sync(); c.step(12000, 0); c.sync(); assert c.first_unstable_step() == -1\n")
+            "with lbm.Context(8192, 2048, inlet_velocity=0.0325, options=dict(tune=0, layout=1, nt=1, alternate=0, fuse=1, arith=1)) as c:\n"
+            "    c.initialise(); c.sync(); c.step(3000, 0); c.sync(); assert c.first_unstable_step() == -1\n")      # (3000 launches of ~0.4 ms: any queue holds them, the wait is the sync)
     out = subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LBM_TRACE=str(trace), LBM_WAIT_TIMEOUT_MS="300"), timeout=170,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    assert "lbm_hip: STALL: hipStreamSynchronize(compute stream) of the strip of rows 0..1024 on device 0, work queued up to iteration 12000" in out.stderr, out.stderr[-500:]
+    assert "lbm_hip: STALL: hipStreamSynchronize(compute stream) of the strip of rows 0..2048 on device 0, work queued up to iteration 3000" in out.stderr, out.stderr[-500:]
     assert any(" STALL " in ln for ln in trace.read_text().splitlines())
 
 
