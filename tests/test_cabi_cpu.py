@@ -170,7 +170,7 @@ def test_group_threads_rendezvous_is_bounded_and_names_the_straggler(pkg):
     rc, done, msg = pool(4, 20, stall=(2, 9, 1500), timeout_ms=200)
     assert rc == -5 and done == 9, (rc, done, msg)
     assert "waited 200 ms at rendezvous 1 of launch 9 of this call for: strip 2 (last seen at rendezvous 1 of launch 8)" in msg, msg
-    assert 0.2 <= time.time() - t0 < 3.0          # the bound, then the teardown waits for the straggler's 1.5 s sleep: no hang, no crash
+    assert 0.2 <= time.time() - t0 < 6.0          # the bound, then the teardown waits for the straggler's 1.5 s sleep: no hang, no crash
     rc, done, msg = pool(3, 5, stall=(0, 2, 600), timeout_ms=150)      # the CALLER's own strip is the slow one: the others time out on it
     assert rc == -5 and "for: strip 0 (last seen at rendezvous 1 of launch 1)" in msg, msg
 

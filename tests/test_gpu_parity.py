@@ -553,12 +553,15 @@ def test_a_stalled_strip_turns_into_a_timeout_that_names_it(lbm):
     kw = dict(inlet_velocity=0.05, cylinder_radius=0.1)
     with lbm.Group(nx, ny, 3, options=dict(PLANS["rowil-fuse3-12-nt-xcd"], wait_timeout_ms=250), **kw) as g:
         g.initialise()
+        g.step(7, 0)                    # (warm: the kernels' code object is loaded before the clock starts)
+        for c in g.ctxs:
+            c.sync()
         for key, v in (("debug_fault_point", 1), ("debug_fault_stall_ms", 1500), ("debug_fault_launch", 1)):
             g.ctxs[2].set_option(key, v)
         t0 = time.time()
         with pytest.raises(lbm.LbmError, match=r"lbm_hip error -5: strip [01] waited 250 ms at rendezvous 2 of launch 1 of this call for: strip 2 \(last seen at rendezvous 1 of launch 1\)"):
             g.step(30, 0)
-        assert time.time() - t0 < 1.2
+        assert time.time() - t0 < 1.4          # back before the straggler's 1.5 s are over
         with pytest.raises(lbm.LbmError, match="timed out earlier"):
             g.step(1, 0)
 
