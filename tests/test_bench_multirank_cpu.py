@@ -86,3 +86,14 @@ def test_eight_ranks_the_shape_of_the_drivers_scaling_run():
     rcs, outs = run_bench("mismatch", world=8, grid=("64", "192"))
     assert rcs == [3] * 8, [o[1][-300:] for o in outs]
 
+
+@pytest.mark.timeout(600)
+def test_weak_scaling_keeps_the_rows_per_gpu():
+    """`--scaling weak`: every rank keeps `--ny` rows (the lattice grows with N), the line says "weak" and is not labelled as a
+    BASELINE.json configuration (the metric is quoted on the fixed 4096x1024 grid: strong scaling)."""
+    rcs, outs = run_bench("ok", world=2, extra=("--scaling", "weak"), grid=("64", "48"))
+    assert rcs == [0, 0], [o[1][-500:] for o in outs]
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][0])
+    assert line["scaling"] == "weak" and line["config"]["ny"] == 96 and line["config"]["rows_per_gpu"] == 48
+    assert "not a BASELINE.json config" in line["config"]["workload"] and line["strips"]["parity"] == "bit-equal"
+
