@@ -205,7 +205,11 @@ struct ChoreoOp {
     int w0[2] = {0, 0}, w1[2] = {0, 0};   // rows written, [w0, w1) in local rows (ghost rows: < 0 or >= nyl); KERNEL: two ranges
     int r0 = 0, r1 = 0, r_strip = -1;     // COPY / SEND / FORCES: rows read and whose (RECV: where the data comes from; -1: another process)
 };
-struct Choreo { std::vector<ChoreoOp> ops; };
+// ... and, for one rank of a multi-process run, the transcript of what exchange_rccl's posting loops WOULD hand to RCCL, in posting order:
+// kind 0 send / 1 recv / 2 end of a group call; `off`, `cnt` in elements of the buffer. lbm_debug_p2p_matching holds the transcripts of
+// neighbouring ranks against each other (RCCL pairs the k-th send to a peer with the peer's k-th receive from the sender).
+struct ChoreoP2P { int kind, peer; long off, cnt; };
+struct Choreo { std::vector<ChoreoOp> ops; std::vector<ChoreoP2P> p2p; };
 
 struct lbm_ctx {
     lbm_params p{};

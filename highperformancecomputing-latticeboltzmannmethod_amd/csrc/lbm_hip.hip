@@ -857,6 +857,76 @@ int lbm_debug_choreography(int nx, int ny, const int* bounds2, int nstrips, int 
     return nbad;
 }
 
+/* TEST HOOK (no device needed): every rank of a multi-process strip run issues its launch groups DRY (as lbm_debug_choreography does for one
+ * rank) and the transcripts of exchange_rccl's posting loops are paired: see include/lbm_hip.h. */
+int lbm_debug_p2p_matching(int nx, int ny, const int* bounds2, int nranks, int precision, const char* options, const char* options_rank1,
+                           const int* calls2, int ncalls, char* out, int cap) {
+    if (!bounds2 || nranks < 2 || !calls2 || ncalls < 1 || (out && cap < 1)) return fail(LBM_ERR_ARG, "bad argument");
+    std::vector<lbm_ctx*> cs;
+    std::vector<Choreo> rec((size_t)nranks);
+    auto cleanup = [&]() { for (lbm_ctx* c : cs) delete c; };
+    auto apply = [&](lbm_ctx* c, const char* opts) -> int {
+        for (const char* q = opts ? opts : ""; *q;) {
+            while (*q == ' ') ++q;
+            const char* eq = strchr(q, '=');
+            if (!eq) break;
+            const std::string key(q, eq);
+            char* end = nullptr;
+            const long v = strtol(eq + 1, &end, 10);
+            const int rc = lbm_set_option(c, key.c_str(), v);
+            if (rc) return rc;
+            q = end;
+        }
+        return LBM_OK;
+    };
+    for (int k = 0; k < nranks; ++k) {
+        lbm_ctx* c = choreo_fake_ctx(nx, ny, bounds2[2 * k], bounds2[2 * k + 1], precision, 0);
+        cs.push_back(c);
+        const int expect = k == 0 ? 0 : cs[(size_t)k - 1]->p.y_start + cs[(size_t)k - 1]->nyl;
+        if (c->nyl < 1 || c->p.y_start != expect || (k + 1 == nranks && expect + c->nyl != ny)) { cleanup(); return fail(LBM_ERR_ARG, "the strips must cover the lattice bottom to top"); }
+        int rc = apply(c, options);
+        if (!rc && k == 1) rc = apply(c, options_rank1);
+        if (rc) { cleanup(); return rc; }
+        c->layout = 1; configure_layout(c, 1);
+        if (c->deep) c->fuse = deep_depth(c->deep);
+        c->comm = (ncclComm_t)(uintptr_t)0x1; c->rank = k; c->nranks = nranks;
+        c->initialised = true; c->cur = 1;
+        c->rec = &rec[(size_t)k];
+        for (int q = 0; q < ncalls && !rc; ++q)
+            rc = DISPATCH(c, do_steps<double>(&c, 1, calls2[2 * q], calls2[2 * q + 1]), do_steps<float>(&c, 1, calls2[2 * q], calls2[2 * q + 1]));
+        if (rc) { cleanup(); return rc; }
+    }
+    std::string text;
+    int bad = 0;
+    auto pick = [&](int r, int kind, int peer) { std::vector<ChoreoP2P> v; for (const ChoreoP2P& p : rec[(size_t)r].p2p) if (p.kind == kind && p.peer == peer) v.push_back(p); return v; };
+    auto groups = [&](int r) { int n = 0; for (const ChoreoP2P& p : rec[(size_t)r].p2p) n += p.kind == 2; return n; };
+    auto pair_up = [&](int from, int to, long from_block, long to_block, const char* what) {
+        const std::vector<ChoreoP2P> S = pick(from, 0, to), R = pick(to, 1, from);
+        char b[256];
+        if (S.size() != R.size()) { ++bad; snprintf(b, sizeof(b), "%s: rank %d posts %zu sends to rank %d, which posts %zu receives from it\n", what, from, S.size(), to, R.size()); text += b; return; }
+        for (size_t k = 0; k < S.size(); ++k)
+            if (S[k].cnt != R[k].cnt || S[k].off - from_block != R[k].off - to_block) {
+                ++bad;
+                if (text.size() < 3000) { snprintf(b, sizeof(b), "%s: message %zu: rank %d sends %ld elements from block offset %ld, rank %d receives %ld at block offset %ld\n", what, k, from,
+                                                   S[k].cnt, S[k].off - from_block, to, R[k].cnt, R[k].off - to_block); text += b; }
+            }
+    };
+    for (int r = 0; r + 1 < nranks; ++r) {
+        const FaceSpans lo = face_spans(cs[(size_t)r]), hi = face_spans(cs[(size_t)r + 1]);
+        pair_up(r, r + 1, lo.top_rows, hi.ghost_s, "northbound");
+        pair_up(r + 1, r, hi.bot_rows, lo.ghost_n, "southbound");
+        if (groups(r) != groups(r + 1)) { ++bad; char b[160]; snprintf(b, sizeof(b), "ranks %d and %d issue %d and %d exchanges\n", r, r + 1, groups(r), groups(r + 1)); text += b; }
+    }
+    {
+        char b[160];
+        snprintf(b, sizeof(b), "%d exchanges per rank, %zu messages posted by rank 0\n", groups(0), rec[0].p2p.size() - (size_t)groups(0));
+        text += b;
+    }
+    if (out) { const size_t m = std::min(text.size(), (size_t)cap - 1); memcpy(out, text.data(), m); out[m] = 0; }
+    cleanup();
+    return bad;
+}
+
 const char* lbm_plan(const lbm_ctx* c) { return c ? c->plan_desc : ""; }
 const char* lbm_plan_options(const lbm_ctx* c) { return c ? c->plan_opts : ""; }
 

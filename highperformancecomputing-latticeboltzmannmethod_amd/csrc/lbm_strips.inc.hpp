@@ -116,7 +116,8 @@ int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
             if (c->rank + 1 < c->nranks) { rec_xfer(c, ChoreoOp::SEND, s, dst, -1, f.top_rows, hr, nullptr); rec_xfer(c, ChoreoOp::RECV, s, dst, f.ghost_n, -1, hr, nullptr); }
             if (c->rank > 0) { rec_xfer(c, ChoreoOp::SEND, s, dst, -1, f.bot_rows, hr, nullptr); rec_xfer(c, ChoreoOp::RECV, s, dst, f.ghost_s, -1, hr, nullptr); }
         }
-        return LBM_OK;
+        if (c->loopback || c->nranks <= 1) return LBM_OK;
+        // (a rank of a multi-process run: the posting loops below run too — dry: what they would hand to RCCL goes to the transcript)
     }
     T* b = static_cast<T*>(c->buf[dst]);
     const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
@@ -149,17 +150,25 @@ int exchange_rccl(lbm_ctx* c, int dst, hipStream_t s) {
     }
     if (c->nranks <= 1) return LBM_OK;
     if (c->layout != 1) return fail(LBM_ERR_COMM, "strips require the row-interleaved layout");
-    // (the k-th send to a peer meets the peer's k-th receive from me: both sides walk the same runs in the same order)
-    NCCLCHK(ncclGroupStart());
+    // (the k-th send to a peer meets the peer's k-th receive from me: both sides walk the same runs in the same order — held on the CPU by
+    // lbm_debug_p2p_matching, which runs these very loops dry on every rank of a run and pairs the transcripts)
+    auto post = [&](int kind, long off, long cnt, int peer) -> int {
+        if (c->rec) { c->rec->p2p.push_back({kind, peer, off, cnt}); return LBM_OK; }
+        if (kind == 0) NCCLCHK(ncclSend(b + off, (size_t)cnt, dt, peer, c->comm, s));
+        else NCCLCHK(ncclRecv(b + off, (size_t)cnt, dt, peer, c->comm, s));
+        return LBM_OK;
+    };
+    if (!c->rec) NCCLCHK(ncclGroupStart());
     if (c->rank + 1 < c->nranks) {
-        for (int k = 0; k < south_runs.n; ++k) NCCLCHK(ncclSend(b + f.top_rows + south_runs.off[k] * sub, south_runs.cnt[k] * sub, dt, c->rank + 1, c->comm, s));
-        for (int k = 0; k < north_runs.n; ++k) NCCLCHK(ncclRecv(b + f.ghost_n + north_runs.off[k] * sub, north_runs.cnt[k] * sub, dt, c->rank + 1, c->comm, s));
+        for (int k = 0; k < south_runs.n; ++k) QCHK(post(0, f.top_rows + (long)(south_runs.off[k] * sub), (long)(south_runs.cnt[k] * sub), c->rank + 1));
+        for (int k = 0; k < north_runs.n; ++k) QCHK(post(1, f.ghost_n + (long)(north_runs.off[k] * sub), (long)(north_runs.cnt[k] * sub), c->rank + 1));
     }
     if (c->rank > 0) {
-        for (int k = 0; k < north_runs.n; ++k) NCCLCHK(ncclSend(b + f.bot_rows + north_runs.off[k] * sub, north_runs.cnt[k] * sub, dt, c->rank - 1, c->comm, s));
-        for (int k = 0; k < south_runs.n; ++k) NCCLCHK(ncclRecv(b + f.ghost_s + south_runs.off[k] * sub, south_runs.cnt[k] * sub, dt, c->rank - 1, c->comm, s));
+        for (int k = 0; k < north_runs.n; ++k) QCHK(post(0, f.bot_rows + (long)(north_runs.off[k] * sub), (long)(north_runs.cnt[k] * sub), c->rank - 1));
+        for (int k = 0; k < south_runs.n; ++k) QCHK(post(1, f.ghost_s + (long)(south_runs.off[k] * sub), (long)(south_runs.cnt[k] * sub), c->rank - 1));
     }
-    NCCLCHK(ncclGroupEnd());
+    if (c->rec) c->rec->p2p.push_back({2, -1, 0, 0});
+    else NCCLCHK(ncclGroupEnd());
     return LBM_OK;
 }
 

@@ -261,6 +261,16 @@ int lbm_debug_group_pool(int n, int rounds, int fail_strip, int fail_round, int 
  * options = "key=value ..." as for lbm_set_option (the plan must be pinned: nothing is measured); calls2 = ncalls x {nsteps, output_frequency}. */
 int lbm_debug_choreography(int nx, int ny, const int* bounds2, int nstrips, int precision, int transport, const char* options,
                            const int* calls2, int ncalls, int dump, char* out, int cap);
+/* Test hook, callable without a device: exchange_rccl's multi-rank branch — the one piece of the library no run has executed yet (it needs two
+ * GPUs) — run DRY on every rank of an `nranks`-process strip run: each rank issues its launch groups as in lbm_debug_choreography and the
+ * posting loops hand their sends / receives (peer, offset, count) to a transcript instead of RCCL. RCCL pairs the k-th send to a peer with the
+ * peer's k-th receive from the sender: the hook checks, for every pair of neighbours and both directions, that the sequences have the same
+ * length and counts and that every message leaves and lands at the same offset inside its block of edge / ghost rows, and that all ranks
+ * issue the same number of exchanges. Returns the number of mismatches (0 = the ranks would pair up) or < 0; `out` describes them.
+ * options: for every rank; options_rank1 (nullable): additionally for rank 1 only — ranks that disagree (e.g. on "halo_trim") must be
+ * flagged. Replaces the tag / count matching of the reference's MPI_Isend / MPI_Irecv pairs (LBMGrid.h:255-276). */
+int lbm_debug_p2p_matching(int nx, int ny, const int* bounds2, int nranks, int precision, const char* options, const char* options_rank1,
+                           const int* calls2, int ncalls, char* out, int cap);
 /* SHA-256 (16 hex digits) of the sources this binary was compiled from (csrc/ and this header); build.py rebuilds
  * when it differs from the tree, bench.py prints it. */
 const char* lbm_build_id(void);

@@ -129,3 +129,47 @@ def test_overwriting_edge_rows_under_a_neighbours_pull_is_flagged(dry):
     assert rc > 0 and "RACE strip 0 buffer" in text and "copy buf" in text and "main stream: kernel" in text, text
     every = dict(tune=0, nt=1, xcd=1, overlap=1, deep_halo=1, deep=7, arith=1)
     assert dry(256, ny, b, 0, dict(every, debug_skip_pull_wait=1), [(40, 0)])[0] == 0
+
+
+def test_the_ranks_of_a_multi_process_run_would_pair_up(dry):
+    """exchange_rccl's multi-rank branch (`nranks > 1`: what replaces Grid::exchange_ghost_cells between processes,
+    /root/reference/include/LBMGrid.h:249-283) has run on no hardware yet — it needs two GPUs. lbm_debug_p2p_matching runs its posting loops
+    DRY on every rank of a run and pairs the transcripts the way RCCL pairs messages (the k-th send to a peer with the peer's k-th receive):
+    same number of messages, same counts, same offset inside the block of edge / ghost rows on both ends, same number of exchanges on every
+    rank — for two to eight ranks, even and uneven strips, every plan family, deep_halo 0/1/2, whole rows and the trimmed message, fp64 and
+    fp32. Ranks that disagree on the message (one trims, one does not) are flagged: the case the pin agreement of lbm_initialise prevents."""
+    pkg = importlib.import_module(PKG)
+    L = C.CDLL(pkg.lib_path())
+    L.lbm_debug_p2p_matching.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int,
+                                         C.c_char_p, C.c_int]
+    L.lbm_last_error.restype = C.c_char_p
+    out = C.create_string_buffer(1 << 14)
+
+    def match(nx, heights, options, calls, precision=0, rank1=None):
+        b, ny = strips_of(heights)
+        ba = (C.c_int * (2 * len(b)))(*[v for p in b for v in p])
+        cl = (C.c_int * (2 * len(calls)))(*[v for p in calls for v in p])
+        rc = L.lbm_debug_p2p_matching(nx, ny, ba, len(b), precision, " ".join(f"{k}={v}" for k, v in options.items()).encode(),
+                                      " ".join(f"{k}={v}" for k, v in rank1.items()).encode() if rank1 else None, cl, len(calls), out, len(out))
+        return rc, (out.value.decode() if rc >= 0 else L.lbm_last_error().decode())
+
+    runs = 0
+    for (plan, prec), dh, trim, ov in itertools.product(PLANS, (0, 1, 2), (0, 1), (0, 1)):
+        opts = dict(tune=0, nt=1, xcd=1, overlap=ov, deep_halo=dh, halo_trim=trim, trailing_pair=1, **plan)
+        for heights in ((128, 128), (40, 24, 100), (12, 13, 14, 200), (128,) * 8):
+            for calls in ([(20, 0)], [(97, 31), (5, 0)]):
+                rc, text = match(4096 if len(heights) == 8 else 320, heights, opts, calls, prec)
+                runs += 1
+                assert rc == 0, f"{opts} {heights} {calls}: rc {rc}\n{text[:2000]}"
+    assert runs > 1000
+    # the payload: six rows x nine sub-rows whole, 45 of them trimmed (nx = 4096 fp64: sub-rows of 4112 elements)
+    rc, text = match(4096, (128,) * 8, dict(tune=0, nt=1, xcd=1, overlap=1, deep_halo=1, deep=1, halo_trim=0, trailing_pair=1), [(24, 0)])
+    assert rc == 0 and "4 exchanges per rank, 8 messages posted by rank 0" in text, text
+    rc, text = match(4096, (128,) * 8, dict(tune=0, nt=1, xcd=1, overlap=1, deep_halo=1, deep=1, halo_trim=1, trailing_pair=1), [(24, 0)])
+    assert rc == 0 and "4 exchanges per rank, 40 messages posted by rank 0" in text, text
+    # negative controls: rank 1 trims and the others do not; rank 1 exchanges twelve rows per two launches and the others six per launch
+    rc, text = match(320, (64, 64, 64), dict(tune=0, nt=1, xcd=1, overlap=1, deep_halo=1, deep=7, halo_trim=0), [(24, 0)], rank1=dict(halo_trim=1))
+    assert rc > 0 and "rank 1 posts" in text, text
+    rc, text = match(320, (64, 64, 64), dict(tune=0, nt=1, xcd=1, overlap=1, deep_halo=1, deep=7, halo_trim=0), [(24, 0)], rank1=dict(deep_halo=2))
+    assert rc > 0, text
+
