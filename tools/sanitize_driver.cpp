@@ -6,6 +6,7 @@
 extern "C" {
 int lbm_debug_group_pool(int n, int rounds, int fail_strip, int fail_round, int stall_strip, int stall_round, int stall_ms, long timeout_ms, int repeat, int* rendezvous_out);
 int lbm_debug_choreography(int nx, int ny, const int* bounds2, int nstrips, int precision, int transport, const char* options, const int* calls2, int ncalls, int dump, char* out, int cap);
+int lbm_debug_p2p_matching(int nx, int ny, const int* bounds2, int nranks, int precision, const char* options, const char* options_rank1, const int* calls2, int ncalls, char* out, int cap);
 const char* lbm_last_error(void);
 }
 int main() {
@@ -30,5 +31,15 @@ int main() {
                     bad += rc != 0; ++runs;
                 }
     printf("choreography: %d dry runs, %d flagged or failed\n", runs, bad);
+    int b8[16], bad2 = 0, runs2 = 0;
+    for (int k = 0; k < 8; ++k) { b8[2 * k] = 128 * k; b8[2 * k + 1] = 128; }
+    for (const char* plan : plans)
+        for (int trim = 0; trim < 2; ++trim) {
+            char opts[160];
+            snprintf(opts, sizeof(opts), "tune=0 nt=1 xcd=1 overlap=1 deep_halo=1 halo_trim=%d trailing_pair=1 %s", trim, plan);
+            rc = lbm_debug_p2p_matching(4096, 1024, b8, 8, 0, opts, nullptr, calls, 1, out, sizeof(out));
+            bad2 += rc != 0; ++runs2;
+        }
+    printf("p2p matching: %d eight-rank dry runs, %d mismatching or failed\n", runs2, bad2);
     return 0;
 }
